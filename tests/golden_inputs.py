@@ -1,0 +1,98 @@
+"""Seeded input recipes shared by oracle/make_goldens.py (fixture generation, build container)
+and the parity tests (CPU + GPU box).  numpy PCG64 streams only -- numpy guarantees
+`default_rng(seed)` bit-streams are stable across versions/platforms, so inputs too big to
+commit (64k K/V) are regenerated instead of stored; fixtures hold the expected outputs.
+"""
+import numpy as np
+
+
+def _rng(*key):
+    return np.random.default_rng(list(key))
+
+
+def randn(rng, *shape):
+    return rng.standard_normal(shape, dtype=np.float32)
+
+
+# g5: test_selection_varlen_semantic.py:46-58 shape (B2 S6 G1 h2 D32 S_kv16, span 3)
+def g5_inputs():
+    r = _rng(5)
+    B, S, G, h, Dk, Dv, S_kv = 2, 6, 1, 2, 32, 32, 16
+    Q, K, V = randn(r, B, S, G, h, Dk), randn(r, B, G, S_kv, Dk), randn(r, B, G, S_kv, Dv)
+    rg = np.zeros((B, S, G, 2, 2), np.int32)
+    for t in range(S):
+        rg[:, t, :, 0, 0] = max(0, t - 3)
+        rg[:, t, :, 0, 1] = min(S_kv, t + 1)
+    return Q, K, V, rg
+
+
+# g6: test_selection_masked_empty_rows.py:6-20
+def g6_inputs():
+    r = _rng(6)
+    Q, K, V = randn(r, 1, 2, 1, 2, 8), randn(r, 1, 1, 4, 8), randn(r, 1, 1, 4, 8)
+    return Q, K, V, np.zeros((1, 2, 1, 1, 2), np.int32)
+
+
+# g7: test_triton_sel_edge_cases.py:23-39 (clamping of out-of-bounds ranges)
+def g7_inputs():
+    r = _rng(7)
+    B, S, G, h, D, S_kv = 1, 1, 1, 2, 16, 16
+    Q, K, V = randn(r, B, S, G, h, D), randn(r, B, G, S_kv, D), randn(r, B, G, S_kv, D)
+    rg = np.array([[-5, -1], [10, 100]], np.int32).reshape(1, 1, 1, 2, 2)
+    return Q, K, V, rg
+
+
+# g8: test_triton_sel_parity_gpu.py:21-37 multi-span
+def g8_inputs():
+    r = _rng(8)
+    B, S, G, h, D, S_kv = 4, 1, 1, 2, 64, 192
+    Q, K, V = randn(r, B, S, G, h, D), randn(r, B, G, S_kv, D), randn(r, B, G, S_kv, D)
+    rg = np.zeros((B, S, G, 3, 2), np.int32)
+    rg[..., 0, :] = (16, 40)
+    rg[..., 1, :] = (64, 96)
+    rg[..., 2, :] = (120, 160)
+    return Q, K, V, rg
+
+
+# g8b: overlapping, unsorted, duplicated, empty and inverted ranges -> union semantics
+def g8b_inputs():
+    r = _rng(88)
+    B, S, G, h, D, S_kv = 2, 3, 2, 3, 32, 100
+    Q, K, V = randn(r, B, S, G, h, D), randn(r, B, G, S_kv, D), randn(r, B, G, S_kv, D)
+    rg = np.zeros((B, S, G, 6, 2), np.int32)
+    rg[:, 0, :] = [[50, 70], [10, 30], [20, 40], [10, 30], [0, 0], [90, 100]]
+    rg[:, 1, :] = [[0, 100], [5, 6], [99, 100], [0, 0], [0, 0], [0, 0]]
+    rg[:, 2, :] = [[30, 31], [31, 32], [95, 250], [60, 60], [-9, 2], [0, 0]]
+    return Q, K, V, rg
+
+
+def g9_scores(S):
+    return _rng(9, S).random((1, S, 2, (S + 63) // 64), dtype=np.float32)
+
+
+def g9_scores_small(S, S_sel):
+    return _rng(90, S).random((2, S, 2, S_sel), dtype=np.float32)
+
+
+# g10: m7c shape (G2 h6 D64, l32 d16 l'64 n16); sampled rows: first 130, every 997th, last 64
+def g10_rows(S):
+    ts = sorted(set(list(range(0, min(130, S))) + list(range(0, S, 997)) + list(range(max(0, S - 64), S))))
+    return np.array(ts, np.int32)
+
+
+def g10_q_kcmp(S, ts, G=2, h=6, D=64):
+    S_cmp = (S - 32) // 16 + 1
+    Kc = randn(_rng(10, S, 1), 1, G, S_cmp, D)
+    Qr = randn(_rng(10, S, 2), 1, len(ts), G, h, D)
+    return Qr, Kc
+
+
+def g10_kv(S, G=2, D=64):
+    r = _rng(10, S, 3)
+    return randn(r, 1, G, S, D), randn(r, 1, G, S, D)
+
+
+def g11_inputs(ci, S, G, h, D, S_cmp):
+    r = _rng(11, ci)
+    B = 2 if S <= 512 else 1
+    return (randn(r, B, S, G, h, D), randn(r, B, G, S_cmp, D), randn(r, B, G, S, D), randn(r, B, G, S, D))
