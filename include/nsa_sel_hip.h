@@ -1,0 +1,156 @@
+/*
+ * nsa_sel_hip.h -- C ABI of libnsa_sel_hip.so: the MI355X (gfx950) implementation of
+ * nsa-vibe's selected-branch attention hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only (no torch types).  Every
+ * pointer is a DEVICE pointer unless its comment says "host".  All kernels are enqueued
+ * on `stream` (a hipStream_t passed as void*; NULL = the default stream) and never
+ * synchronise.  Inputs are borrowed and never written; outputs are caller allocated.
+ *
+ * Error convention (replaces the Python exceptions of the reference's plugin slot,
+ * nsa/kernels/cuda_sel_kernel/__init__.py:60-68 and nsa/core/nsa_attention.py:764-782):
+ * every entry point returns 0 on success, a negative NSA_ERR_* code otherwise, and
+ * nsa_hip_last_error() returns a thread-local message.  The Python shim raises
+ * RuntimeError on non-zero, which is what the reference's router catches.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   nsa_sel_attn_fwd           sel_forward(Q,K,V,ranges)            nsa/kernels/cuda_sel_kernel/sel_cuda.cpp:28-73
+ *                              selection_attention_cuda             nsa/kernels/cuda_sel_kernel/__init__.py:47-68
+ *                              grouped_selection_attention_masked   nsa/core/attention_kernels.py:705-772 (semantics)
+ *   nsa_sel_attn_bwd           analytic backward / autograd of the masked SDPA
+ *                                                                   nsa/kernels/triton_sel_kernel/__init__.py:125-231
+ *   nsa_sel_scores             compute_pcmp_all + map_pcmp_to_pslc_batched + .sum(dim=3)
+ *                                                                   nsa/core/selection_scorer.py:42-61, 89-116; nsa_attention.py:1073-1091
+ *   nsa_pcmp_all               compute_pcmp_all                     nsa/core/selection_scorer.py:42-61
+ *   nsa_map_pcmp_to_pgrp       map_pcmp_to_pslc_batched + group sum nsa/core/selection_scorer.py:89-121
+ *   nsa_select_topn_ranges     select_topn_ranges / _batched (+v2)  nsa/core/selection_scorer.py:124-249, 255-362, 434-605
+ *   nsa_indices_to_ranges_v2   convert_indices_to_ranges_batched_v2 nsa/core/selection_scorer.py:434-605
+ *   nsa_batched_ranges_width   forced-column rule of the batched selector  selection_scorer.py:283-308,339-354
+ *   nsa_build_block_meta_host  build_block_meta                     nsa/core/block_index.py:74-99
+ */
+#ifndef NSA_SEL_HIP_H
+#define NSA_SEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSA_HIP_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define NSA_API __attribute__((visibility("default")))
+#else
+#define NSA_API
+#endif
+
+/* element types of Q/K/V/O */
+#define NSA_DT_F32 0
+#define NSA_DT_BF16 1
+#define NSA_DT_F16 2
+
+/* selector semantics */
+#define NSA_SEL_SEQUENTIAL 0 /* select_topn_ranges        (decode, sequential prefill) */
+#define NSA_SEL_BATCHED 1    /* select_topn_ranges_batched (batched prefill, training)  */
+
+/* error codes */
+#define NSA_OK 0
+#define NSA_ERR_INVALID (-1)     /* bad argument / unsupported shape */
+#define NSA_ERR_HIP (-2)         /* a HIP runtime call failed        */
+#define NSA_ERR_WORKSPACE (-3)   /* workspace too small              */
+#define NSA_ERR_NO_DEVICE (-4)   /* no gfx950 device                 */
+
+NSA_API int nsa_hip_abi_version(void);
+NSA_API const char *nsa_hip_last_error(void);
+/* 0 if device `dev` is a gfx950 part; fills cu_count / total memory (host pointers, nullable). */
+NSA_API int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes);
+
+/* ---------------------------------------------------------------------------------------
+ * Selection attention forward.
+ *   Q [B,S,G,h,Dk]  O [B,S,G,h,Dv]   contiguous
+ *   K [B,G,S_kv,Dk] V [B,G,S_kv,Dv]  innermost dim contiguous; the b/g/token strides are given in
+ *                                    ELEMENTS so a preallocated cache [B,G,S_max,D] can be passed
+ *                                    without a copy (NSA_KV layout, nsa/cache/kv_cache.py:8-30)
+ *   ranges [B,S,G,n,2] int32 [start,end) token ranges.  Semantics = union of the ranges after
+ *          clamping to [0,S_kv] (attention_kernels.py:721-732); end<=start entries are ignored;
+ *          a row with no allowed token yields zeros (attention_kernels.py:734-749,769-771).
+ *   lse    [B,S,G,h] fp32, nullable: log-sum-exp of the scaled logits (needed by the backward).
+ *   scale  softmax scale; pass <=0 for the default Dk^-1/2.
+ *   variant 0 = auto, 1 = generic VALU kernel, 2 = MFMA kernel (bf16/f16, Dk=Dv in {64,128}, h<=16).
+ *   workspace: nsa_sel_attn_fwd_workspace() bytes (may be 0); used when few rows are split over KV.
+ * ------------------------------------------------------------------------------------- */
+NSA_API size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype);
+NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O,
+                     float *lse, int B, int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges,
+                     int64_t k_stride_b, int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b,
+                     int64_t v_stride_g, int64_t v_stride_s, int dtype, float scale, int variant,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward.  dO like O; dQ like Q (dtype); dK/dV are fp32 [B,G,S_kv,D] contiguous accumulators that
+ * the callee zero-fills first (one fp32 atomic add per selected (row,token) element).
+ * O and lse come from the forward. */
+NSA_API int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t *ranges, const void *O,
+                     const float *lse, const void *dO, void *dQ, float *dK, float *dV, int B, int S,
+                     int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t k_stride_b,
+                     int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b, int64_t v_stride_g,
+                     int64_t v_stride_s, int dtype, float scale, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Eq.9 map in gather (CSC) form.  For selection block j the entries csc_ptr[j]..csc_ptr[j+1]
+ * list (cmp row, weight) in ASCENDING cmp row -- the order the reference's CPU scatter_add
+ * accumulates in -- so p_slc is bit-identical to the reference given an identical fp32 p_cmp.
+ * nsa_build_block_meta_host fills both the reference's CSR/COO arrays and this CSC (host
+ * pointers; call with NULL arrays to get the sizes).
+ * ------------------------------------------------------------------------------------- */
+NSA_API int nsa_block_counts(int seq_len, int l, int d, int l_sel, int *S_cmp, int *S_sel, int *nnz);
+NSA_API int nsa_build_block_meta_host(int seq_len, int l, int d, int l_sel, int32_t *csr_indptr /*S_cmp+1*/,
+                              int32_t *csr_indices /*nnz*/, float *csr_values /*nnz*/,
+                              int32_t *csc_ptr /*S_sel+1*/, int32_t *csc_rows /*nnz*/,
+                              float *csc_vals /*nnz*/);
+
+/* p_cmp [R,h,S_cmp_cur] fp32 -> p_slc [R,h,S_sel] (nullable) and p_grp [R,S_sel] (Eq.10, heads
+ * summed in ascending h).  CSC rows >= S_cmp_cur are dropped (selection_scorer.py:103-108). */
+NSA_API int nsa_map_pcmp_to_pgrp(const float *p_cmp, int64_t R, int h, int S_cmp_cur, const int32_t *csc_ptr,
+                         const int32_t *csc_rows, const float *csc_vals, int S_sel, float *p_slc,
+                         float *p_grp, void *stream);
+
+/* p_cmp = softmax over ALL S_cmp columns of Q K_cmp^T * scale, fp32 out [B,S,G,h,S_cmp].
+ * Q [B,S,G,h,Dk] contiguous; K_cmp [B,G,S_cmp,Dk] with element strides. */
+NSA_API int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, int S, int G, int h, int Dk,
+                 int S_cmp, int64_t kc_stride_b, int64_t kc_stride_g, int64_t kc_stride_s, int dtype,
+                 float scale, void *stream);
+
+/* Fused scorer: Q,K_cmp -> p_grp [B,S,G,S_sel] fp32 without materialising p_cmp / p_slc.
+ * workspace: nsa_sel_scores_workspace() bytes. */
+NSA_API size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int S_cmp, int S_sel);
+NSA_API int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk,
+                   int S_cmp, int64_t kc_stride_b, int64_t kc_stride_g, int64_t kc_stride_s,
+                   const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel,
+                   int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Deterministic top-n + forced blocks + range merge.
+ *   p_grp [R,S_sel] fp32 with R = B*S*G rows ordered (b,s,g); row r sits at token
+ *   t = t0 + (r / G) % S  (decode: S = 1, t0 = current position), or t_rows[r] if non-NULL.
+ *   mode NSA_SEL_SEQUENTIAL: out [R,n_top,2]; mode NSA_SEL_BATCHED: out [R,K,2] with
+ *   K = nsa_batched_ranges_width(...); out_width must equal that width.
+ *   Ranking key = fp32(p) - fp32(idx)*1e-8f (unfused), descending, index ascending on ties.
+ *   Sequential-mode note: where the reference's topk would have to pick -inf entries (fewer valid
+ *   candidates than n_top - 3) it emits inverted garbage ranges; this ABI emits [0,0] instead.
+ * ------------------------------------------------------------------------------------- */
+NSA_API int nsa_batched_ranges_width(int S, int S_sel, int l_sel, int n_top, int force_init, int force_local);
+NSA_API int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, int t0, const int32_t *t_rows,
+                           int S_sel, int l_sel, int n_top, int force_init, int force_local, int mode,
+                           int S_total /* batched: the S the forced-column rule is evaluated for */,
+                           int32_t *ranges_out, int out_width, void *stream);
+
+/* indices [R,K] int32 ascending with -1 padding -> ranges [R,K,2]; clamp end to t+1. */
+NSA_API int nsa_indices_to_ranges_v2(const int32_t *indices, int64_t R, int S, int G, int t0, int K, int S_sel,
+                             int l_sel, int32_t *ranges_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSA_SEL_HIP_H */

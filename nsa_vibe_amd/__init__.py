@@ -1,0 +1,29 @@
+"""nsa_vibe_amd -- MI355X (gfx950) implementation of nsa-vibe's selected-branch attention hot path.
+
+Host side = PyTorch-ROCm plumbing that mirrors the reference's operator surface
+(nsa/core/{block_index,selection_scorer,attention_kernels}.py, nsa/kernels/cuda_sel_kernel);
+the arithmetic lives in hand-written HIP kernels behind the C ABI include/nsa_sel_hip.h
+(libnsa_sel_hip.so).  There is no CPU or eager fallback: a missing library raises.
+"""
+from . import _lib  # noqa: F401
+from .block_index import BlockMeta, build_block_meta, build_block_starts, build_M_csl_csr  # noqa: F401
+from .selection_attention import (  # noqa: F401
+    grouped_selection_attention_masked,
+    hip_sel_available,
+    selection_attention_hip,
+)
+from .selection_scorer import (  # noqa: F401
+    batched_ranges_width,
+    compute_pcmp_all,
+    convert_indices_to_ranges_batched_v2,
+    group_reduce_pslc,
+    map_pcmp_to_pgrp,
+    map_pcmp_to_pslc,
+    map_pcmp_to_pslc_batched,
+    select_topn_ranges,
+    select_topn_ranges_batched,
+    select_topn_ranges_rows,
+    selection_scores,
+)
+
+__version__ = "0.1.0"

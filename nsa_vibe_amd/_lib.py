@@ -1,0 +1,79 @@
+"""ctypes binding of libnsa_sel_hip.so (C ABI: include/nsa_sel_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback behind it.  If it is missing
+or a call fails this module raises (ImportError / RuntimeError) -- loudly, by design.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsa_sel_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+NSA_DT_F32, NSA_DT_BF16, NSA_DT_F16 = 0, 1, 2
+NSA_SEL_SEQUENTIAL, NSA_SEL_BATCHED = 0, 1
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nsa_sel_hip.h one to one
+SIGNATURES = {
+    "nsa_hip_abi_version": (_i, []),
+    "nsa_hip_last_error": (C.c_char_p, []),
+    "nsa_hip_device_check": (_i, [_i, C.POINTER(_i), C.POINTER(_sz)]),
+    "nsa_sel_attn_fwd_workspace": (_sz, [_i] * 8),
+    "nsa_sel_attn_fwd": (_i, [_vp] * 6 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
+    "nsa_sel_attn_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),
+    "nsa_block_counts": (_i, [_i] * 4 + [C.POINTER(_i)] * 3),
+    "nsa_build_block_meta_host": (_i, [_i] * 4 + [_vp] * 6),
+    "nsa_map_pcmp_to_pgrp": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "nsa_pcmp_all": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_i, _f, _vp]),
+    "nsa_sel_scores_workspace": (_sz, [_i] * 6),
+    "nsa_sel_scores": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
+    "nsa_batched_ranges_width": (_i, [_i] * 6),
+    "nsa_select_topn_ranges": (_i, [_vp, _i64, _i, _i, _i, _vp] + [_i] * 7 + [_vp, _i, _vp]),
+    "nsa_indices_to_ranges_v2": (_i, [_vp, _i64] + [_i] * 6 + [_vp, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    r = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libnsa_sel_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+def lib():
+    """Load the C-ABI library (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is required (no fallback path exists). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C nsa_vibe_amd/csrc`.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.nsa_hip_abi_version() != 1:
+            raise ImportError("libnsa_sel_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().nsa_hip_last_error() or b"").decode()
+
+
+def check(rc: int, what: str) -> None:
+    """Non-zero status -> RuntimeError (the exception type the reference's router catches,
+    nsa/kernels/cuda_sel_kernel/__init__.py:60-68)."""
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (status {rc}): {last_error()}")

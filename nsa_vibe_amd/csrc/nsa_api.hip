@@ -1,0 +1,283 @@
+// C ABI of libnsa_sel_hip.so (see include/nsa_sel_hip.h).  Host-side argument checking,
+// error reporting and kernel dispatch; no torch types, no allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <vector>
+
+#include "nsa_common.hpp"
+#include "sel_attn_params.hpp"
+
+namespace nsa {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return NSA_ERR_HIP;
+}
+
+// implemented in the kernel translation units
+int launch_select_topn(const float *, int64_t, int, int, int, const int32_t *, int, int, int, int, int, int, int,
+                       int32_t *, int, hipStream_t);
+int launch_indices_to_ranges(const int32_t *, int64_t, int, int, int, int, int, int, int32_t *, hipStream_t);
+int batched_width(int, int, int, int, int, int);
+int launch_map_pcmp(const float *, int64_t, int, int, const int32_t *, const int32_t *, const float *, int, float *,
+                    float *, hipStream_t);
+int launch_pcmp(const void *, const void *, float *, int64_t, int64_t, int, int, int, int, int, int64_t, int64_t,
+                int64_t, int, float, hipStream_t);
+size_t scores_workspace(int64_t, int, int);
+int launch_sel_scores(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t,
+                      const int32_t *, const int32_t *, const float *, int, int, float, void *, size_t, hipStream_t);
+
+static bool dtype_ok(int dt) { return dt == NSA_DT_F32 || dt == NSA_DT_BF16 || dt == NSA_DT_F16; }
+
+}  // namespace nsa
+
+using namespace nsa;
+
+extern "C" {
+
+int nsa_hip_abi_version(void) { return NSA_HIP_ABI_VERSION; }
+
+const char *nsa_hip_last_error(void) { return g_err; }
+
+int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= dev || dev < 0) {
+        set_error("no HIP device %d (count %d)", dev, n);
+        return NSA_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    NSA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+        return NSA_ERR_NO_DEVICE;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return NSA_OK;
+}
+
+// ------------------------------------------------------------------------------ attention
+size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype) {
+    (void)n_ranges;
+    if (!sel_attn_mfma_supported(dtype, h, Dk, Dv)) return 0;
+    return sel_attn_mfma_workspace((int64_t)B * S * G, h, Dv, nullptr);
+}
+
+int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, float *lse, int B,
+                     int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg,
+                     int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, int variant,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_attn_fwd: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0 && n_ranges >= 0,
+                  "sel_attn_fwd: negative size");
+    NSA_CHECK_ARG(n_ranges <= 64, "sel_attn_fwd: at most 64 ranges per row are supported (got %d)", n_ranges);
+    NSA_CHECK_ARG(Dk <= 256 && Dv <= 256, "sel_attn_fwd: Dk/Dv up to 256 supported (got %d/%d)", Dk, Dv);
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    NSA_CHECK_ARG(Q && O && ranges || n_ranges == 0, "sel_attn_fwd: null pointer");
+    NSA_CHECK_ARG((K && V) || S_kv == 0, "sel_attn_fwd: null K/V");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = dtype == NSA_DT_F32 ? 4 : 2;
+    if (S_kv == 0 || n_ranges == 0) {  // attention_kernels.py:718-719
+        NSA_HIP_TRY(hipMemsetAsync(O, 0, (size_t)R * h * Dv * esz, st));
+        if (lse) {
+            std::vector<float> neg;  // lse = -inf: fill with the bit pattern 0xff800000
+            NSA_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)lse, (int)0xff800000, (size_t)R * h, st));
+        }
+        return NSA_OK;
+    }
+    SelAttnParams P{};
+    P.Q = Q; P.K = K; P.V = V; P.ranges = ranges; P.O = O; P.lse = lse; P.R = R;
+    P.S = S; P.G = G; P.h = h; P.Dk = Dk; P.Dv = Dv; P.S_kv = S_kv; P.n = n_ranges;
+    P.ksb = ksb; P.ksg = ksg; P.kss = kss; P.vsb = vsb; P.vsg = vsg; P.vss = vss;
+    P.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    P.part = nullptr; P.nsplit = 1;
+    const bool fast_ok = sel_attn_mfma_supported(dtype, h, Dk, Dv) && kss % 8 == 0 && vss % 8 == 0 && ksb % 8 == 0 &&
+                         vsb % 8 == 0 && ksg % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) &&
+                         ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0);
+    if (variant == 2) NSA_CHECK_ARG(fast_ok, "sel_attn_fwd: MFMA variant requested but shape/dtype/alignment unsupported");
+    NSA_CHECK_ARG(variant >= 0 && variant <= 2, "sel_attn_fwd: unknown variant %d", variant);
+    if (variant == 2 || (variant == 0 && fast_ok)) {
+        int ns = 1;
+        const size_t need = sel_attn_mfma_workspace(R, h, Dv, &ns);
+        if (ns > 1 && workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0)) {
+            P.part = (float *)workspace;
+            P.nsplit = ns;
+        }
+        return launch_sel_attn_fwd_mfma(P, dtype, st);
+    }
+    return launch_sel_attn_fwd_generic(P, dtype, st);
+}
+
+int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t *ranges, const void *O,
+                     const float *lse, const void *dO, void *dQ, float *dK, float *dV, int B, int S, int G, int h,
+                     int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
+                     int64_t vsg, int64_t vss, int dtype, float scale, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_attn_bwd: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0 && n_ranges >= 0,
+                  "sel_attn_bwd: negative size");
+    NSA_CHECK_ARG(n_ranges <= 64, "sel_attn_bwd: at most 64 ranges per row");
+    NSA_CHECK_ARG(Dk <= 256 && Dv <= 256, "sel_attn_bwd: Dk/Dv up to 256 supported");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t R = (int64_t)B * S * G;
+    const size_t esz = dtype == NSA_DT_F32 ? 4 : 2;
+    if ((int64_t)B * G * S_kv > 0) {
+        NSA_HIP_TRY(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)B * G * S_kv * Dk, st));
+        NSA_HIP_TRY(hipMemsetAsync(dV, 0, sizeof(float) * (size_t)B * G * S_kv * Dv, st));
+    }
+    if (R == 0) return NSA_OK;
+    if (S_kv == 0 || n_ranges == 0) {
+        NSA_HIP_TRY(hipMemsetAsync(dQ, 0, (size_t)R * h * Dk * esz, st));
+        return NSA_OK;
+    }
+    NSA_CHECK_ARG(Q && K && V && ranges && O && lse && dO && dQ && dK && dV, "sel_attn_bwd: null pointer");
+    SelAttnBwdParams P{};
+    P.Q = Q; P.K = K; P.V = V; P.ranges = ranges; P.O = O; P.lse = lse; P.dO = dO; P.dQ = dQ; P.dK = dK; P.dV = dV;
+    P.R = R; P.S = S; P.G = G; P.h = h; P.Dk = Dk; P.Dv = Dv; P.S_kv = S_kv; P.n = n_ranges;
+    P.ksb = ksb; P.ksg = ksg; P.kss = kss; P.vsb = vsb; P.vsg = vsg; P.vss = vss;
+    P.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    return launch_sel_attn_bwd_generic(P, dtype, st);
+}
+
+// ------------------------------------------------------------------------------ block meta (host)
+int nsa_block_counts(int seq_len, int l, int d, int l_sel, int *S_cmp, int *S_sel, int *nnz) {
+    NSA_CHECK_ARG(l > 0 && d > 0 && l_sel > 0, "Block parameters must be positive");
+    NSA_CHECK_ARG(l % d == 0 && l_sel % d == 0, "Require d|l and d|l_sel in M0");  // block_index.py:75-77
+    const int sc = seq_len < l ? 0 : (seq_len - l) / d + 1;
+    const int ss = seq_len <= 0 ? 0 : (seq_len + l_sel - 1) / l_sel;
+    if (S_cmp) *S_cmp = sc;
+    if (S_sel) *S_sel = ss;
+    if (nnz) {
+        // cmp block i = [i d, i d + l) overlaps selection blocks floor(i d / l') .. floor((i d + l - 1) / l'), capped
+        int64_t cnt = 0;
+        for (int i = 0; i < sc; ++i) {
+            const int j0 = (i * d) / l_sel;
+            int j1 = (i * d + l - 1) / l_sel;
+            if (j1 > ss - 1) j1 = ss - 1;
+            if (j1 >= j0) cnt += j1 - j0 + 1;
+        }
+        *nnz = (int)cnt;
+    }
+    return NSA_OK;
+}
+
+// Closed form of build_M_csl_csr (block_index.py:43-71): O(nnz) instead of the reference's
+// O(S_cmp * S_sel) double loop.  Weight = overlap / total overlap, evaluated in double and
+// rounded once to fp32 exactly as torch.tensor(python floats, dtype=float32) does.
+int nsa_build_block_meta_host(int seq_len, int l, int d, int l_sel, int32_t *csr_indptr, int32_t *csr_indices,
+                              float *csr_values, int32_t *csc_ptr, int32_t *csc_rows, float *csc_vals) {
+    int sc, ss, nnz;
+    int rc = nsa_block_counts(seq_len, l, d, l_sel, &sc, &ss, &nnz);
+    if (rc) return rc;
+    std::vector<int32_t> ind((size_t)nnz), rows((size_t)nnz);
+    std::vector<float> val((size_t)nnz);
+    std::vector<int32_t> iptr((size_t)sc + 1, 0);
+    int k = 0;
+    for (int i = 0; i < sc; ++i) {
+        const int a0 = i * d, a1 = i * d + l;
+        const int j0 = a0 / l_sel;
+        int j1 = (a1 - 1) / l_sel;
+        if (j1 > ss - 1) j1 = ss - 1;
+        int total = 0;
+        for (int j = j0; j <= j1; ++j) {
+            const int lo = a0 > j * l_sel ? a0 : j * l_sel;
+            const int hi = a1 < (j + 1) * l_sel ? a1 : (j + 1) * l_sel;
+            total += hi - lo;
+        }
+        for (int j = j0; j <= j1; ++j) {
+            const int lo = a0 > j * l_sel ? a0 : j * l_sel;
+            const int hi = a1 < (j + 1) * l_sel ? a1 : (j + 1) * l_sel;
+            ind[k] = j;
+            rows[k] = i;
+            val[k] = (float)((double)(hi - lo) / (double)total);
+            ++k;
+        }
+        iptr[(size_t)i + 1] = k;
+    }
+    if (csr_indptr) memcpy(csr_indptr, iptr.data(), sizeof(int32_t) * ((size_t)sc + 1));
+    if (csr_indices && nnz) memcpy(csr_indices, ind.data(), sizeof(int32_t) * (size_t)nnz);
+    if (csr_values && nnz) memcpy(csr_values, val.data(), sizeof(float) * (size_t)nnz);
+    if (csc_ptr) {
+        // counting sort by column; stable in the row index => ascending cmp row inside each column
+        std::vector<int32_t> cnt((size_t)ss + 1, 0);
+        for (int e = 0; e < nnz; ++e) cnt[(size_t)ind[e] + 1]++;
+        for (int j = 0; j < ss; ++j) cnt[(size_t)j + 1] += cnt[j];
+        memcpy(csc_ptr, cnt.data(), sizeof(int32_t) * ((size_t)ss + 1));
+        if (csc_rows && csc_vals) {
+            std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+            for (int e = 0; e < nnz; ++e) {
+                const int p = pos[ind[e]]++;
+                csc_rows[p] = rows[e];
+                csc_vals[p] = val[e];
+            }
+        }
+    }
+    return NSA_OK;
+}
+
+// ------------------------------------------------------------------------------ scores
+int nsa_map_pcmp_to_pgrp(const float *p_cmp, int64_t R, int h, int S_cmp_cur, const int32_t *csc_ptr,
+                         const int32_t *csc_rows, const float *csc_vals, int S_sel, float *p_slc, float *p_grp,
+                         void *stream) {
+    NSA_CHECK_ARG(p_grp && csc_ptr, "map_pcmp_to_pgrp: null pointer");
+    return launch_map_pcmp(p_cmp, R, h, S_cmp_cur, csc_ptr, csc_rows, csc_vals, S_sel, p_slc, p_grp, (hipStream_t)stream);
+}
+
+int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, int S, int G, int h, int Dk, int S_cmp,
+                 int64_t csb, int64_t csg, int64_t css, int dtype, float scale, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "pcmp_all: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1, "pcmp_all: bad sizes");
+    if (scale <= 0.f) scale = 1.0f / sqrtf((float)Dk);
+    return launch_pcmp(Q, K_cmp, p_cmp, 0, (int64_t)B * S * G, S, G, h, Dk, S_cmp, csb, csg, css, dtype, scale,
+                       (hipStream_t)stream);
+}
+
+size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int S_cmp, int S_sel) {
+    (void)S_sel;
+    return scores_workspace((int64_t)B * S * G, h, S_cmp);
+}
+
+int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp,
+                   int64_t csb, int64_t csg, int64_t css, const int32_t *csc_ptr, const int32_t *csc_rows,
+                   const float *csc_vals, int S_sel, int dtype, float scale, void *workspace, size_t workspace_bytes,
+                   void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_scores: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1, "sel_scores: bad sizes");
+    if (scale <= 0.f) scale = 1.0f / sqrtf((float)Dk);
+    return launch_sel_scores(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel,
+                             dtype, scale, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------ selection
+int nsa_batched_ranges_width(int S, int S_sel, int l_sel, int n_top, int force_init, int force_local) {
+    return batched_width(S, S_sel, l_sel, n_top, force_init, force_local);
+}
+
+int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, int t0, const int32_t *t_rows, int S_sel,
+                           int l_sel, int n_top, int force_init, int force_local, int mode, int S_total,
+                           int32_t *ranges_out, int out_width, void *stream) {
+    NSA_CHECK_ARG(p_grp && ranges_out || R == 0, "select_topn_ranges: null pointer");
+    return launch_select_topn(p_grp, R, S, G, t0, t_rows, S_sel, l_sel, n_top, force_init, force_local, mode, S_total,
+                              ranges_out, out_width, (hipStream_t)stream);
+}
+
+int nsa_indices_to_ranges_v2(const int32_t *indices, int64_t R, int S, int G, int t0, int K, int S_sel, int l_sel,
+                             int32_t *ranges_out, void *stream) {
+    NSA_CHECK_ARG((indices && ranges_out) || R == 0 || K == 0, "indices_to_ranges_v2: null pointer");
+    NSA_CHECK_ARG(S >= 1 && G >= 1, "indices_to_ranges_v2: bad sizes");
+    return launch_indices_to_ranges(indices, R, S, G, t0, K, S_sel, l_sel, ranges_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

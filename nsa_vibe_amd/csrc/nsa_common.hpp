@@ -1,0 +1,171 @@
+// Shared device/host helpers for libnsa_sel_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nsa_sel_hip.h"
+
+namespace nsa {
+
+// ---- error plumbing (host) -------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define NSA_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::nsa::set_error(__VA_ARGS__); \
+            return NSA_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+#define NSA_HIP_TRY(expr)                                                   \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return ::nsa::hip_fail(_e, #expr);            \
+    } while (0)
+
+#define NSA_LAUNCH_CHECK(name)                                              \
+    do {                                                                    \
+        hipError_t _e = hipGetLastError();                                  \
+        if (_e != hipSuccess) return ::nsa::hip_fail(_e, name " launch");   \
+    } while (0)
+
+// ---- vector types ----------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// ---- element traits --------------------------------------------------------------------
+template <typename T>
+struct Elt;
+template <>
+struct Elt<float> {
+    static constexpr int dt = NSA_DT_F32;
+    __device__ static float to_f(float x) { return x; }
+    __device__ static float from_f(float x) { return x; }
+};
+template <>
+struct Elt<__bf16> {
+    static constexpr int dt = NSA_DT_BF16;
+    __device__ static float to_f(__bf16 x) { return (float)x; }
+    __device__ static __bf16 from_f(float x) { return (__bf16)x; }
+};
+template <>
+struct Elt<_Float16> {
+    static constexpr int dt = NSA_DT_F16;
+    __device__ static float to_f(_Float16 x) { return (float)x; }
+    __device__ static _Float16 from_f(float x) { return (_Float16)x; }
+};
+
+// ---- wave helpers ----------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// make LDS traffic of this wave visible to its own later LDS reads (wave-private regions only:
+// DS operations of one wave execute in order, the fence only pins the compiler).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------
+// Range normalisation (one wave per query row).
+//   Reference semantics (attention_kernels.py:721-732): clamp start/end to [0,S_kv], allowed =
+//   union of the ranges; entries with end <= start contribute nothing (every other executor and
+//   sel_cuda.cpp:16-18 skip them).  The union is produced as sorted, disjoint segments so the
+//   kernels can walk tokens in ascending order without touching a token twice.
+//   seg[] lives in wave-private LDS: seg[2*i] = start, seg[2*i+1] = exclusive prefix length,
+//   seg[2*nseg+1] holds the total.  Supports n <= 64 ranges.
+// Returns the total number of selected tokens L (wave uniform); *nseg_out = number of segments
+// (including empty ones; empty segments have equal consecutive prefix offsets).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int normalise_ranges(const int32_t *__restrict__ rg, int n, int S_kv, int *seg,
+                                                int *nseg_out) {
+    const int lane = lane_id();
+    int s = 0, e = 0;
+    if (lane < n) {
+        s = rg[2 * lane];
+        e = rg[2 * lane + 1];
+        s = min(max(s, 0), S_kv);
+        e = min(max(e, 0), S_kv);
+    }
+    const bool valid = e > s;
+    // rank sort by (start, lane) among valid entries
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        int sj = __shfl(s, j, 64);
+        int ej = __shfl(e, j, 64);
+        bool vj = ej > sj;
+        rank += (vj && (sj < s || (sj == s && j < lane))) ? 1 : 0;
+    }
+    const int nvalid = __popcll(__ballot(valid));
+    // scatter to sorted order through LDS (reuse seg as scratch: [0..63] starts, [64..127] ends)
+    if (valid) {
+        seg[rank] = s;
+        seg[64 + rank] = e;
+    }
+    wave_lds_fence();
+    int ss = 0, se = 0;
+    if (lane < nvalid) {
+        ss = seg[lane];
+        se = seg[64 + lane];
+    }
+    wave_lds_fence();
+    // exclusive running max of the ends -> effective start
+    int run = (lane < nvalid) ? se : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(run, o, 64);
+        if (lane >= o) run = max(run, v);
+    }
+    int prev = __shfl_up(run, 1, 64);
+    if (lane == 0) prev = 0;
+    int es = max(ss, prev);
+    int len = (lane < nvalid) ? max(se - es, 0) : 0;
+    int inc = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    const int total = __shfl(inc, 63, 64);
+    if (lane < nvalid) {
+        seg[2 * lane] = es;
+        seg[2 * lane + 1] = inc - len;
+    }
+    if (lane == 0) {
+        seg[2 * nvalid] = 0;
+        seg[2 * nvalid + 1] = total;
+    }
+    wave_lds_fence();
+    *nseg_out = nvalid;
+    return total;
+}
+constexpr int SEG_INTS = 132;  // LDS ints needed by normalise_ranges per wave (>= 2*64+2, and 128 scratch)
+
+}  // namespace nsa

@@ -1,0 +1,45 @@
+// Kernel argument blocks for the selection-attention kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsa {
+
+struct SelAttnParams {
+    const void *Q;          // [R,h,Dk]   (R = B*S*G rows, row = (b*S+s)*G+g)
+    const void *K;          // [B,G,S_kv,Dk] with element strides ksb/ksg/kss
+    const void *V;          // [B,G,S_kv,Dv] with element strides vsb/vsg/vss
+    const int32_t *ranges;  // [R,n,2]
+    void *O;                // [R,h,Dv]
+    float *lse;             // [R,h] or null
+    int64_t R;
+    int S, G, h, Dk, Dv, S_kv, n;
+    int64_t ksb, ksg, kss, vsb, vsg, vss;
+    float scale;
+    // split-KV (few rows): partial results, see sel_attn_mfma.hip
+    float *part;  // workspace or null
+    int nsplit;
+};
+
+struct SelAttnBwdParams {
+    const void *Q, *K, *V;
+    const int32_t *ranges;
+    const void *O;
+    const float *lse;
+    const void *dO;
+    void *dQ;
+    float *dK, *dV;
+    int64_t R;
+    int S, G, h, Dk, Dv, S_kv, n;
+    int64_t ksb, ksg, kss, vsb, vsg, vss;
+    float scale;
+};
+
+int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);
+int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_t st);
+// returns NSA_ERR_INVALID (without setting an error) when the shape is not covered
+bool sel_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
+int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st);
+size_t sel_attn_mfma_workspace(int64_t R, int h, int Dv, int *nsplit_out);
+
+}  // namespace nsa

@@ -1,0 +1,281 @@
+// Deterministic top-n + forced blocks + range merge: one wave64 per (b,t,g) row.
+//
+// Reference: select_topn_ranges (nsa/core/selection_scorer.py:124-249, decode / sequential prefill)
+// and select_topn_ranges_batched + convert_indices_to_ranges_batched_v2 (:255-362, :434-605).
+//
+// Per row the selected set is kept as a bitmap over selection blocks (bit per block, lane l owns
+// blocks l, l+64, l+128, ...), which makes the reference's "concat forced + top-k, sort, drop
+// duplicates, merge adjacent" a run extraction on the bitmap:
+//   * candidate key  = fp32(p) - fp32(idx) * 1e-8f, multiply and subtract rounded separately
+//     (selection_scorer.py:182-184; __fmul_rn/__fsub_rn so hipcc cannot contract to an FMA);
+//   * k picks by iterative wave arg-max on (key desc, idx asc) with xor shuffles; picking stops
+//     when only -inf keys remain (the reference then picks arbitrary -inf entries, which are
+//     either duplicates of forced blocks or future blocks it drops / emits as garbage);
+//   * runs of the bitmap are emitted in ascending order as [start*l', min((end+1)*l', t+1)).
+#include "nsa_common.hpp"
+
+namespace nsa {
+
+struct SelectParams {
+    const float *p_grp;     // [R,S_sel]
+    const int32_t *t_rows;  // [R] or null
+    int32_t *out;           // [R,W,2]
+    int64_t R;
+    int S, G, t0, S_sel, l_sel, n_top, force_init, force_local, mode, W;
+    int k_actual;      // picks per row
+    int n_forced;      // forced entries used (sequential: all; batched: kept columns, maybe truncated)
+    unsigned keepmask; // batched: bit i = sorted forced column i is kept
+    int all_valid;     // batched with n_top >= S_sel: select every valid block
+};
+
+template <int CAND>
+__global__ __launch_bounds__(256) void select_topn_kernel(SelectParams P) {
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P.R) return;
+    const int t = P.t_rows ? P.t_rows[row] : P.t0 + (int)((row / P.G) % P.S);
+    const int l_sel = P.l_sel, S_sel = P.S_sel;
+    const float *p = P.p_grp + row * (int64_t)S_sel;
+    const int nvalid_blocks = min(S_sel, (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
+
+    float key[CAND];
+    unsigned selbits = 0;  // bit c = block lane + 64 c selected
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        const int j = lane + 64 * c;
+        float k = -INFINITY;
+        if (j < nvalid_blocks) k = __fsub_rn(p[j], __fmul_rn((float)j, 1e-8f));
+        key[c] = k;
+        if (P.all_valid && j < nvalid_blocks) selbits |= 1u << c;
+    }
+
+    if (!P.all_valid) {
+        // ---- forced blocks
+        const int cblk = max(t / l_sel, 0);
+        const int nf_all = (P.force_init ? 1 : 0) + P.force_local;
+        int used = 0;
+        for (int i = 0; i < nf_all; ++i) {
+            // sorted forced list: [0 (init)] then max(cblk - a, 0) with a descending to 0
+            int f;
+            if (P.force_init && i == 0) f = 0;
+            else f = max(cblk - (nf_all - 1 - i), 0);
+            if (P.mode == NSA_SEL_BATCHED) {
+                if (!((P.keepmask >> i) & 1u)) continue;
+                if (used >= P.n_forced) break;
+            }
+            ++used;
+            if (f >= S_sel) continue;
+            const bool valid = f < nvalid_blocks;
+            if ((f & 63) == lane) {
+                const int c = f >> 6;
+#pragma unroll
+                for (int cc = 0; cc < CAND; ++cc)
+                    if (cc == c) {
+                        key[cc] = -INFINITY;                                              // excluded from top-k
+                        if (P.mode == NSA_SEL_SEQUENTIAL || valid) selbits |= 1u << cc;   // batched drops invalid picks
+                    }
+            }
+        }
+        // ---- top-k picks
+        for (int it = 0; it < P.k_actual; ++it) {
+            float bk = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < CAND; ++c)
+                if (key[c] > bk) {  // ascending c = ascending idx within the lane: strict > keeps the lowest idx
+                    bk = key[c];
+                    bi = lane + 64 * c;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ok = __shfl_xor(bk, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ok > bk || (ok == bk && oi < bi)) {
+                    bk = ok;
+                    bi = oi;
+                }
+            }
+            if (bk == -INFINITY) break;  // wave uniform
+            if ((bi & 63) == lane) {
+                const int c = bi >> 6;
+#pragma unroll
+                for (int cc = 0; cc < CAND; ++cc)
+                    if (cc == c) {
+                        key[cc] = -INFINITY;
+                        selbits |= 1u << cc;
+                    }
+            }
+        }
+    }
+
+    // ---- run extraction
+    int32_t *out = P.out + row * (int64_t)P.W * 2;
+    int my_s = 0, my_e = 0;
+    int nrun = 0;
+    int cur_s = -1, cur_e = -1;  // pending run (block ids), wave uniform
+    auto emit = [&]() {
+        if (nrun == lane) {
+            my_s = cur_s * l_sel;
+            my_e = min((cur_e + 1) * l_sel, t + 1);
+        }
+        ++nrun;
+    };
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        unsigned long long w = __ballot((selbits >> c) & 1u);
+        while (w) {  // maximal runs of ones of this word, ascending
+            const int sb = __builtin_ctzll(w);
+            const unsigned long long inv = ~(w >> sb);
+            const int len = inv ? __builtin_ctzll(inv) : 64;
+            const unsigned long long ones = (len == 64) ? ~0ull : ((1ull << len) - 1ull);
+            w &= ~(ones << sb);
+            const int s_blk = 64 * c + sb, e_blk = s_blk + len - 1;
+            if (cur_s >= 0 && s_blk == cur_e + 1) {
+                cur_e = e_blk;  // run continues across the word boundary
+            } else {
+                if (cur_s >= 0) emit();
+                cur_s = s_blk;
+                cur_e = e_blk;
+            }
+        }
+    }
+    if (cur_s >= 0) emit();
+    if (lane < P.W) {
+        out[2 * lane] = my_s;
+        out[2 * lane + 1] = my_e;
+    }
+    // rows wider than a wave (W > 64 only when n_top >= S_sel > 64: a single run) -> zero the rest
+    for (int i = lane + 64; i < P.W; i += 64) {
+        out[2 * i] = 0;
+        out[2 * i + 1] = 0;
+    }
+}
+
+// ---- v2 converter alone: one thread per row -------------------------------------------------
+struct ConvParams {
+    const int32_t *idx;
+    int32_t *out;
+    int64_t R;
+    int S, G, t0, K, S_sel, l_sel;
+};
+
+__global__ __launch_bounds__(256) void indices_to_ranges_kernel(ConvParams P) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= P.R) return;
+    const int t = P.t0 + (int)((row / P.G) % P.S);
+    const int32_t *x = P.idx + row * (int64_t)P.K;
+    int32_t *out = P.out + row * (int64_t)P.K * 2;
+    for (int i = 0; i < 2 * P.K; ++i) out[i] = 0;
+    int m = 0, i = 0;
+    while (i < P.K) {
+        if (x[i] < 0) {
+            ++i;
+            continue;
+        }
+        const int first = x[i];
+        int last = x[i];
+        int j = i + 1;
+        while (j < P.K && x[j] >= 0 && (x[j] - x[j - 1] == 0 || x[j] - x[j - 1] == 1)) {
+            last = max(last, x[j]);
+            ++j;
+        }
+        if (first < P.S_sel && last < P.S_sel) {
+            out[2 * m] = first * P.l_sel;
+            out[2 * m + 1] = min(last * P.l_sel + P.l_sel, t + 1);
+        }
+        ++m;
+        i = j;
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------
+// forced-column rule of the batched selector (selection_scorer.py:283-300), closed form:
+// sorted per-row forced list = [0 (init)] + [max(c - a, 0) for a = fl-1 .. 0], c = t // l';
+// torch.unique_consecutive(dim=-1) drops column i iff it equals column i-1 for EVERY t in [0,S),
+// i.e. iff c_max = (S-1)//l' <= a_i.
+unsigned batched_keepmask(int S, int l_sel, int force_init, int force_local, int *n_kept) {
+    const int nf = (force_init ? 1 : 0) + (force_local > 0 ? force_local : 0);
+    const int cmax = S > 0 ? (S - 1) / l_sel : 0;
+    unsigned mask = 0;
+    int kept = 0;
+    for (int i = 0; i < nf && i < 32; ++i) {
+        bool keep;
+        if (i == 0) keep = true;
+        else {
+            const int a = nf - 1 - i;  // this column is max(c - a, 0)
+            keep = cmax > a;
+        }
+        if (keep) {
+            mask |= 1u << i;
+            ++kept;
+        }
+    }
+    if (n_kept) *n_kept = kept;
+    return mask;
+}
+
+int batched_width(int S, int S_sel, int l_sel, int n_top, int force_init, int force_local) {
+    int nfc;
+    batched_keepmask(S, l_sel, force_init, force_local, &nfc);
+    const int k_rest = n_top - nfc > 0 ? n_top - nfc : 0;
+    const int k_actual = k_rest < S_sel ? k_rest : S_sel;
+    if (n_top >= S_sel) return S_sel;
+    if (k_rest > 0) return nfc + k_actual;
+    return nfc < n_top ? nfc : n_top;
+}
+
+int launch_select_topn(const float *p_grp, int64_t R, int S, int G, int t0, const int32_t *t_rows, int S_sel,
+                       int l_sel, int n_top, int force_init, int force_local, int mode, int S_total,
+                       int32_t *out, int W, hipStream_t st) {
+    NSA_CHECK_ARG(R >= 0 && S >= 1 && G >= 1 && S_sel >= 1 && l_sel >= 1 && n_top >= 0, "select: bad sizes");
+    NSA_CHECK_ARG(S_sel <= 64 * 32, "select: S_sel=%d exceeds 2048 selection blocks", S_sel);
+    NSA_CHECK_ARG(force_local >= 0 && force_local <= 30, "select: force_local out of range");
+    SelectParams P{};
+    P.p_grp = p_grp; P.t_rows = t_rows; P.out = out; P.R = R; P.S = S; P.G = G; P.t0 = t0; P.S_sel = S_sel;
+    P.l_sel = l_sel; P.n_top = n_top; P.force_init = force_init ? 1 : 0; P.force_local = force_local; P.mode = mode;
+    P.W = W;
+    const int nf_all = P.force_init + force_local;
+    if (mode == NSA_SEL_SEQUENTIAL) {
+        NSA_CHECK_ARG(W == n_top, "select (sequential): out_width must be n_top");
+        const int k_rest = n_top - nf_all > 0 ? n_top - nf_all : 0;
+        P.k_actual = k_rest < S_sel ? k_rest : S_sel;
+        P.n_forced = nf_all;
+        P.keepmask = 0xffffffffu;
+        P.all_valid = 0;
+    } else if (mode == NSA_SEL_BATCHED) {
+        int nfc;
+        P.keepmask = batched_keepmask(S_total, l_sel, force_init, force_local, &nfc);
+        NSA_CHECK_ARG(W == batched_width(S_total, S_sel, l_sel, n_top, force_init, force_local),
+                      "select (batched): out_width %d != nsa_batched_ranges_width()", W);
+        const int k_rest = n_top - nfc > 0 ? n_top - nfc : 0;
+        P.k_actual = k_rest < S_sel ? k_rest : S_sel;
+        P.n_forced = k_rest > 0 ? nfc : (nfc < n_top ? nfc : n_top);
+        P.all_valid = n_top >= S_sel ? 1 : 0;
+    } else {
+        NSA_CHECK_ARG(false, "select: unknown mode %d", mode);
+    }
+    if (R == 0 || W == 0) return NSA_OK;
+    const unsigned grid = (unsigned)((R + 3) / 4);
+    const int cand = (S_sel + 63) / 64;
+#define NSA_SEL_LAUNCH(C) hipLaunchKernelGGL(select_topn_kernel<C>, dim3(grid), dim3(256), 0, st, P)
+    if (cand <= 1) NSA_SEL_LAUNCH(1);
+    else if (cand <= 2) NSA_SEL_LAUNCH(2);
+    else if (cand <= 4) NSA_SEL_LAUNCH(4);
+    else if (cand <= 8) NSA_SEL_LAUNCH(8);
+    else if (cand <= 16) NSA_SEL_LAUNCH(16);
+    else NSA_SEL_LAUNCH(32);
+#undef NSA_SEL_LAUNCH
+    NSA_LAUNCH_CHECK("select_topn");
+    return NSA_OK;
+}
+
+int launch_indices_to_ranges(const int32_t *idx, int64_t R, int S, int G, int t0, int K, int S_sel, int l_sel,
+                             int32_t *out, hipStream_t st) {
+    if (R == 0 || K == 0) return NSA_OK;
+    ConvParams P{idx, out, R, S, G, t0, K, S_sel, l_sel};
+    hipLaunchKernelGGL(indices_to_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, P);
+    NSA_LAUNCH_CHECK("indices_to_ranges");
+    return NSA_OK;
+}
+
+}  // namespace nsa

@@ -1,0 +1,118 @@
+"""Selection attention executor on MI355X: `selection_attention_hip(Q, K, V, ranges)`.
+
+Same call signature and result layout as every selection executor of the reference
+(nsa/core/attention_kernels.py:181-186,273-278,391-396,705-710 and the native slot
+nsa/kernels/cuda_sel_kernel/__init__.py:47-52):
+
+    Q [B,S,G,h,Dk], K [B,G,S_kv,Dk], V [B,G,S_kv,Dv], ranges [B,S,G,n,2] int32/int64
+    -> O [B,S,G,h,Dv] in V's dtype, on V's device.
+
+Semantics = the reference's masked path (attention_kernels.py:705-772): softmax over the UNION
+of the clamped ranges, non-causal inside the selected set, empty rows -> zeros.  Inputs are
+borrowed (the caller's ranges tensor is never modified -- the reference clamps an int64 ranges
+tensor in place, attention_kernels.py:723-724).  Differentiable: backward runs the HIP backward
+kernel (dQ, dK, dV) with P recomputed from the forward's log-sum-exp.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .selection_scorer import _DT, _need_gpu, _stream, workspace
+
+
+def _prep_kv(X: torch.Tensor) -> torch.Tensor:
+    return X if X.stride(-1) == 1 else X.contiguous()
+
+
+def _prep_ranges(ranges: torch.Tensor) -> torch.Tensor:
+    if ranges.dtype != torch.int32:
+        ranges = ranges.to(torch.int32)  # a copy: the caller's tensor stays untouched
+    return ranges.contiguous()
+
+
+def _fwd(Q, K, V, ranges, scale, variant, want_lse):
+    dev = _need_gpu(Q, K, V, ranges)
+    if not (Q.dtype == K.dtype == V.dtype) or Q.dtype not in _DT:
+        raise RuntimeError(f"selection_attention_hip: Q/K/V must share a dtype in fp32/bf16/fp16 (got {Q.dtype},{K.dtype},{V.dtype})")
+    if Q.dim() != 5 or K.dim() != 4 or V.dim() != 4 or ranges.dim() != 5 or ranges.shape[-1] != 2:
+        raise RuntimeError("selection_attention_hip: expected Q[B,S,G,h,Dk] K[B,G,S_kv,Dk] V[B,G,S_kv,Dv] ranges[B,S,G,n,2]")
+    B, S, G, h, Dk = Q.shape
+    S_kv, Dv = K.shape[2], V.shape[3]
+    n = ranges.shape[3]
+    if K.shape[:2] != (B, G) or V.shape[:3] != (B, G, S_kv) or K.shape[3] != Dk or ranges.shape[:3] != (B, S, G):
+        raise RuntimeError("selection_attention_hip: inconsistent shapes")
+    Qc, Kc, Vc, rg = Q.contiguous(), _prep_kv(K), _prep_kv(V), _prep_ranges(ranges)
+    O = torch.empty((B, S, G, h, Dv), dtype=V.dtype, device=dev)
+    lse = torch.empty((B, S, G, h), dtype=torch.float32, device=dev) if want_lse else None
+    if O.numel() == 0:
+        return O, lse, (Qc, Kc, Vc, rg)
+    L = _lib.lib()
+    dt = _DT[Q.dtype]
+    ws = workspace(dev, L.nsa_sel_attn_fwd_workspace(B, S, G, h, Dk, Dv, n, dt), "attn")
+    rc = L.nsa_sel_attn_fwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(),
+                            lse.data_ptr() if lse is not None else None, B, S, G, h, Dk, Dv, S_kv, n,
+                            Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
+                            dt, float(scale) if scale else 0.0, int(variant),
+                            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
+    _lib.check(rc, "nsa_sel_attn_fwd")
+    return O, lse, (Qc, Kc, Vc, rg)
+
+
+class _SelAttnFn(torch.autograd.Function):
+    """autograd wrapper (pattern of the reference's Triton wrapper,
+    nsa/kernels/triton_sel_kernel/__init__.py:125-142: save Q,K,V,ranges; backward -> dQ,dK,dV,None)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, ranges, scale, variant):
+        O, lse, (Qc, Kc, Vc, rg) = _fwd(Q, K, V, ranges, scale, variant, True)
+        ctx.save_for_backward(Qc, Kc, Vc, rg, O, lse)
+        ctx.scale = scale
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Qc, Kc, Vc, rg, O, lse = ctx.saved_tensors
+        dev = Qc.device
+        B, S, G, h, Dk = Qc.shape
+        S_kv, Dv = Kc.shape[2], Vc.shape[3]
+        dO = dO.contiguous()
+        dQ = torch.empty_like(Qc)
+        dK = torch.empty((B, G, S_kv, Dk), dtype=torch.float32, device=dev)
+        dV = torch.empty((B, G, S_kv, Dv), dtype=torch.float32, device=dev)
+        rc = _lib.lib().nsa_sel_attn_bwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(),
+                                         lse.data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                                         B, S, G, h, Dk, Dv, S_kv, rg.shape[3],
+                                         Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
+                                         _DT[Qc.dtype], float(ctx.scale) if ctx.scale else 0.0, _stream(dev))
+        _lib.check(rc, "nsa_sel_attn_bwd")
+        return dQ, dK.to(Kc.dtype), dV.to(Vc.dtype), None, None, None
+
+
+def selection_attention_hip(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, ranges: torch.Tensor, *,
+                            scale: Optional[float] = None, variant: int = 0, return_lse: bool = False):
+    """The MI355X selection executor (drop-in for selection_attention_cuda / grouped_selection_attention_masked).
+
+    variant: 0 auto (MFMA kernel when dtype/shape allow, else the generic kernel), 1 generic, 2 MFMA."""
+    if torch.is_grad_enabled() and (Q.requires_grad or K.requires_grad or V.requires_grad):
+        if return_lse:
+            raise RuntimeError("return_lse is not available on the autograd path")
+        return _SelAttnFn.apply(Q, K, V, ranges, scale, variant)
+    O, lse, _ = _fwd(Q, K, V, ranges, scale, variant, return_lse)
+    return (O, lse) if return_lse else O
+
+
+# the reference's executor names, bound to the HIP implementation
+grouped_selection_attention_masked = selection_attention_hip
+selection_attention_cuda = selection_attention_hip
+
+
+def hip_sel_available() -> bool:
+    """Counterpart of cuda_sel_available() (nsa/kernels/cuda_sel_kernel/__init__.py:43-44)."""
+    try:
+        _lib.lib()
+    except (ImportError, OSError, AttributeError):
+        return False
+    return torch.cuda.is_available()

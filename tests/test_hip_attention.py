@@ -1,0 +1,254 @@
+"""GPU parity: selection attention (HIP, through the C ABI) vs the oracle and the golden vectors.
+
+Tolerances (BASELINE.json north_star): |O - ref| <= 1e-3 for fp32 inputs, <= 1e-2 for bf16/fp16
+(reference = the masked-SDPA semantics, nsa/core/attention_kernels.py:705-772)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 1e-2}
+
+
+@pytest.fixture(scope="module")
+def nv():
+    import nsa_vibe_amd
+
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return nsa_vibe_amd
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rounded(a, dtype):
+    """numpy fp32 array rounded through `dtype` (what the kernel actually sees)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).float().numpy()
+
+
+def run_case(nv, orc, Q, K, V, rg, dtype, variant, tol=None):
+    qd, kd, vd = dev(Q, dtype), dev(K, dtype), dev(V, dtype)
+    O, lse = nv.selection_attention_hip(qd, kd, vd, dev(rg), variant=variant, return_lse=True)
+    assert O.dtype == dtype and O.shape == (*Q.shape[:4], V.shape[3])
+    ref, ref_lse = orc.sel_attention_masked(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), rg, return_lse=True)
+    got = O.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= (tol or TOL[dtype]), f"max|dO|={err:.3e} dtype={dtype} variant={variant}"
+    fin = np.isfinite(ref_lse)
+    lg = lse.cpu().numpy()
+    assert np.array_equal(np.isfinite(lg), fin)
+    if fin.any():
+        assert np.abs(lg[fin] - ref_lse[fin]).max() <= 2e-2
+    return got
+
+
+@pytest.mark.parametrize("case", ["g5", "g6", "g7", "g8", "g8b"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_golden_cases_generic(nv, orc, case, dtype):
+    g = load_golden("g5_8_attention")
+    Q, K, V, rg = getattr(gi, case + "_inputs")()
+    got = run_case(nv, orc, Q, K, V, rg, dtype, variant=1)
+    if dtype == torch.float32:  # directly against the reference's own output
+        assert np.abs(got - g[case + "_O"]).max() <= 1e-3
+    if case == "g6":
+        assert not got.any()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_golden_g8_mfma(nv, orc, dtype):
+    g = load_golden("g5_8_attention")
+    Q, K, V, rg = gi.g8_inputs()  # D=64, h=2, multi-span
+    got = run_case(nv, orc, Q, K, V, rg, dtype, variant=2)
+    if dtype == torch.bfloat16:  # the reference's own bf16 result
+        assert np.abs(got - g["g8_O_bf16"]).max() <= 1e-2
+
+
+def test_ranges_int64_not_mutated(nv):
+    Q, K, V, rg = gi.g7_inputs()
+    r64 = dev(rg).long()
+    keep = r64.clone()
+    nv.selection_attention_hip(dev(Q), dev(K), dev(V), r64)
+    assert torch.equal(r64, keep)  # the reference clamps an int64 ranges tensor in place; we must not
+
+
+def _rand_ranges(rng, B, S, G, n, S_kv, aligned=False):
+    rg = np.zeros((B, S, G, n, 2), np.int32)
+    for idx in np.ndindex(B, S, G):
+        k = rng.integers(0, n + 1)
+        for i in range(k):
+            if aligned:
+                s = int(rng.integers(0, max(1, S_kv // 64))) * 64
+                e = min(S_kv, s + 64 * int(rng.integers(1, 3)))
+            else:
+                s = int(rng.integers(0, S_kv))
+                e = int(min(S_kv, s + rng.integers(0, 150)))
+            rg[idx][i] = (s, e)
+    return rg
+
+
+@pytest.mark.parametrize("h,D", [(6, 64), (1, 64), (16, 64), (4, 128), (12, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mfma_random_shapes(nv, orc, h, D, dtype):
+    rng = np.random.default_rng([h, D])
+    B, S, G, n, S_kv = 2, 9, 2, 7, 700
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv)
+    rg[0, 0, 0] = 0  # an empty row
+    rg[0, 1, 0, 0] = (5, 6)  # a single token
+    rg[0, 2, 0, :2] = [(0, 700), (100, 200)]  # whole sequence + contained range
+    run_case(nv, orc, Q, K, V, rg, dtype, variant=2)
+    run_case(nv, orc, Q, K, V, rg, dtype, variant=1)
+
+
+def test_mfma_matches_generic_many_rows(nv):
+    """R large enough that no split-KV is used; aligned 64-token blocks like the real selector."""
+    rng = np.random.default_rng(77)
+    B, S, G, h, D, n, S_kv = 2, 600, 2, 6, 64, 16, 2048
+    Q = torch.from_numpy(rng.standard_normal((B, S, G, h, D), dtype=np.float32)).cuda().bfloat16()
+    K = torch.from_numpy(rng.standard_normal((B, G, S_kv, D), dtype=np.float32)).cuda().bfloat16()
+    V = torch.from_numpy(rng.standard_normal((B, G, S_kv, D), dtype=np.float32)).cuda().bfloat16()
+    rg = dev(_rand_ranges(rng, B, S, G, n, S_kv, aligned=True))
+    O2 = nv.selection_attention_hip(Q, K, V, rg, variant=2).float()
+    O1 = nv.selection_attention_hip(Q, K, V, rg, variant=1).float()
+    assert (O2 - O1).abs().max().item() <= 1e-2
+
+
+def test_split_kv_few_rows(nv, orc):
+    """decode shape: B*G rows only -> tiles of a row are split over several waves + combine."""
+    rng = np.random.default_rng(5)
+    B, S, G, h, D, n, S_kv = 2, 1, 2, 6, 64, 16, 4096
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv, aligned=True)
+    rg[1, 0, 1] = 0  # empty row through the split path
+    rg[0, 0, 1, :] = 0
+    rg[0, 0, 1, 0] = (4000, 4001)  # fewer tiles than splits
+    run_case(nv, orc, Q, K, V, rg, torch.bfloat16, variant=2)
+
+
+def test_strided_cache_view(nv, orc):
+    """K/V passed as views of a preallocated [B,G,S_max,D] cache (no copy; NSA_KV layout)."""
+    rng = np.random.default_rng(9)
+    B, S, G, h, D, S_kv, S_max = 1, 5, 2, 6, 64, 300, 512
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    Kf = rng.standard_normal((B, G, S_max, D), dtype=np.float32)
+    Vf = rng.standard_normal((B, G, S_max, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, 5, S_kv)
+    for dtype, variant in ((torch.bfloat16, 2), (torch.float32, 1)):
+        Kc, Vc = dev(Kf, dtype), dev(Vf, dtype)
+        O = nv.selection_attention_hip(dev(Q, dtype), Kc[:, :, :S_kv], Vc[:, :, :S_kv], dev(rg), variant=variant)
+        ref = orc.sel_attention_masked(rounded(Q, dtype), rounded(Kf[:, :, :S_kv], dtype), rounded(Vf[:, :, :S_kv], dtype), rg)
+        assert np.abs(O.float().cpu().numpy() - ref).max() <= TOL[dtype]
+
+
+def test_degenerate_sizes(nv):
+    z = nv.selection_attention_hip(torch.zeros(1, 2, 1, 2, 8).cuda(), torch.zeros(1, 1, 0, 8).cuda(), torch.zeros(1, 1, 0, 8).cuda(),
+                                   torch.zeros(1, 2, 1, 3, 2, dtype=torch.int32).cuda())
+    assert z.shape == (1, 2, 1, 2, 8) and not z.any()
+    z = nv.selection_attention_hip(torch.zeros(0, 2, 1, 2, 8).cuda(), torch.zeros(0, 1, 4, 8).cuda(), torch.zeros(0, 1, 4, 8).cuda(),
+                                   torch.zeros(0, 2, 1, 3, 2, dtype=torch.int32).cuda())
+    assert z.numel() == 0
+    with pytest.raises(RuntimeError):  # more ranges per row than the kernels support -> status code -> RuntimeError
+        nv.selection_attention_hip(torch.zeros(1, 1, 1, 1, 8).cuda(), torch.zeros(1, 1, 4, 8).cuda(), torch.zeros(1, 1, 4, 8).cuda(),
+                                   torch.zeros(1, 1, 1, 65, 2, dtype=torch.int32).cuda())
+    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+        nv.selection_attention_hip(torch.zeros(1, 1, 1, 1, 8), torch.zeros(1, 1, 4, 8), torch.zeros(1, 1, 4, 8),
+                                   torch.zeros(1, 1, 1, 1, 2, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("S", [4096, 16384, 65536])
+def test_g10_m7c_rows(nv, orc, S):
+    """m7c shape at the BASELINE sequence lengths, sampled rows, against the reference's outputs."""
+    g = load_golden(f"g10_m7c_S{S}")
+    ts = gi.g10_rows(S)
+    Qr, _ = gi.g10_q_kcmp(S, ts)
+    K, V = gi.g10_kv(S)
+    rg = g["r_bat"][None]
+    # fp32, generic kernel, directly against the reference's fp32 output
+    O32 = nv.selection_attention_hip(dev(Qr), dev(K), dev(V), dev(rg), variant=1).cpu().numpy()
+    assert np.abs(O32[0] - g["O_bat"]).max() <= 1e-3
+    # bf16, MFMA kernel: against the reference's fp32 output (input rounding included in the 1e-2 bar)
+    Ob = nv.selection_attention_hip(dev(Qr, torch.bfloat16), dev(K, torch.bfloat16), dev(V, torch.bfloat16), dev(rg), variant=2)
+    refb = orc.sel_attention_masked(rounded(Qr, torch.bfloat16), rounded(K, torch.bfloat16), rounded(V, torch.bfloat16), rg)
+    assert np.abs(Ob.float().cpu().numpy() - refb).max() <= 1e-2
+    assert np.abs(Ob.float().cpu().numpy()[0] - g["O_bat"]).max() <= 3e-2
+    # sequential-mode ranges (normalised: inverted garbage entries removed)
+    rs = g["r_seq"].copy()
+    rs[rs[..., 1] <= rs[..., 0]] = 0
+    Os = nv.selection_attention_hip(dev(Qr), dev(K), dev(V), dev(rs[None]), variant=1).cpu().numpy()
+    assert np.abs(Os[0] - g["O_seq"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("dtype,variant", [(torch.float32, 1), (torch.bfloat16, 1)])
+def test_backward_vs_oracle(nv, orc, dtype, variant):
+    rng = np.random.default_rng(21)
+    B, S, G, h, D, S_kv, n = 2, 7, 2, 3, 32, 90, 4
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    dO = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv)
+    rg[0, 0, 0] = 0
+    q, k, v = (dev(x, dtype).requires_grad_(True) for x in (Q, K, V))
+    O = nv.selection_attention_hip(q, k, v, dev(rg), variant=variant)
+    O.backward(dev(dO, dtype))
+    rq, rk, rv = orc.sel_attention_masked_bwd(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), rg, rounded(dO, dtype))
+    tol = 2e-3 if dtype == torch.float32 else 6e-2
+    for got, ref, name in ((q.grad, rq, "dQ"), (k.grad, rk, "dK"), (v.grad, rv, "dV")):
+        err = np.abs(got.float().cpu().numpy() - ref).max()
+        assert err <= tol * max(1.0, np.abs(ref).max()), f"{name} err {err:.3e}"
+
+
+def test_backward_m7c_shape_bf16(nv, orc):
+    rng = np.random.default_rng(22)
+    B, S, G, h, D, S_kv, n = 1, 6, 2, 6, 64, 512, 5
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    dO = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv, aligned=True)
+    dt = torch.bfloat16
+    q, k, v = (dev(x, dt).requires_grad_(True) for x in (Q, K, V))
+    nv.selection_attention_hip(q, k, v, dev(rg)).backward(dev(dO, dt))  # forward = MFMA kernel (auto)
+    rq, rk, rv = orc.sel_attention_masked_bwd(rounded(Q, dt), rounded(K, dt), rounded(V, dt), rg, rounded(dO, dt))
+    for got, ref in ((q.grad, rq), (k.grad, rk), (v.grad, rv)):
+        assert np.abs(got.float().cpu().numpy() - ref).max() <= 6e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_properties_full_size_64k(nv):
+    """Size-independent properties at the BASELINE full size (S=65536, m7c, bf16, every row)."""
+    torch.manual_seed(0)
+    B, S, G, h, D, n = 1, 65536, 2, 6, 64, 16
+    Q = torch.randn(B, S, G, h, D, device="cuda", dtype=torch.bfloat16)
+    K = torch.randn(B, G, S, D, device="cuda", dtype=torch.bfloat16)
+    V = torch.randn(B, G, S, D, device="cuda", dtype=torch.bfloat16)
+    p = torch.rand(B, S, G, S // 64, device="cuda")
+    meta = nv.build_block_meta(S, 32, 16, 64, n, 512)
+    rg = nv.select_topn_ranges_batched(p, meta, n, S)
+    O = nv.selection_attention_hip(Q, K, V, rg).float()
+    assert torch.isfinite(O).all()
+    # convex combination of V rows: |O| bounded by max |V| (+ bf16 rounding)
+    assert O.abs().max().item() <= V.float().abs().max().item() * 1.01
+    # rows with no complete block (t < 63) are empty in batched mode -> zeros
+    assert not O[:, :63].any()
+    # range order does not matter (union semantics): reverse the range list
+    O_rev = nv.selection_attention_hip(Q, K, V, rg.flip(3)).float()
+    assert (O - O_rev).abs().max().item() <= 1e-2
+    # linearity in V
+    V2 = torch.randn_like(V)
+    O2 = nv.selection_attention_hip(Q, K, V2, rg).float()
+    O12 = nv.selection_attention_hip(Q, K, (V.float() + V2.float()).bfloat16(), rg).float()
+    assert (O12 - (O + O2)).abs().max().item() <= 6e-2
+    # duplicated ranges change nothing
+    O_dup = nv.selection_attention_hip(Q, K, V, torch.cat([rg, rg], dim=3)).float()
+    assert (O - O_dup).abs().max().item() <= 1e-2
