@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the selected-branch attention hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch of synthetic input for one layer:
+    Q,K_cmp -> p_grp (softmax scores, Eq.9, Eq.10) -> deterministic top-n ranges -> selection attention
+on the m7c_125m shape (dim 768: 12 heads, G=2, h=6, d_k=d_v=64; l=32 d=16 l'=64 n=16), S=4096, bf16,
+B sequences per GPU (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.
+Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequences, no data-path
+collective exists on this path (weak scaling); time = max over ranks.
+
+The JSON line also carries
+  roofline     dominant kernel (selection attention): algorithmic gather bytes / HIP-event kernel time
+               vs the 8 TB/s HBM peak (L_row*(Dk+Dv)*sizeof per (b,t,g) row)
+  cpu_baseline the CPU oracle (a port of the reference path, validated against the reference) timed on
+               this node's host cores on a bounded sample of the same workload
+  extra        decode tok/s and prefill ms at S in {4k,16k,64k}, MFMA TFLOP/s of the attention kernel
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+G, H, D = 2, 6, 64
+L_CMP, D_CMP, L_SEL, N_SEL = 32, 16, 64, 16
+
+
+def make_inputs(nv, B, S, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    meta = nv.build_block_meta(S, L_CMP, D_CMP, L_SEL, N_SEL, 512)
+    Q = torch.randn(B, S, G, H, D, device=device, generator=g).bfloat16()
+    Kc = torch.randn(B, G, meta.S_cmp, D, device=device, generator=g).bfloat16()
+    K = torch.randn(B, G, S, D, device=device, generator=g).bfloat16()
+    V = torch.randn(B, G, S, D, device=device, generator=g).bfloat16()
+    return meta, Q, Kc, K, V
+
+
+def hot_path(nv, meta, Q, Kc, K, V, S):
+    p_grp = nv.selection_scores(Q, Kc, meta)
+    ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
+    O = nv.selection_attention_hip(Q, K, V, ranges)
+    return ranges, O
+
+
+def time_events(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
+
+
+def stage_times(nv, meta, Q, Kc, K, V, S, iters):
+    p_grp = nv.selection_scores(Q, Kc, meta)
+    ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
+    t_sc = time_events(lambda: nv.selection_scores(Q, Kc, meta), iters)
+    t_sel = time_events(lambda: nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S), iters)
+    t_att = time_events(lambda: nv.selection_attention_hip(Q, K, V, ranges), iters)
+    L = (ranges[..., 1] - ranges[..., 0]).clamp_min(0).sum(-1).double()
+    return t_sc, t_sel, t_att, float(L.sum().item()), float(L.mean().item())
+
+
+def decode_bench(nv, B, S_ctx, steps, device):
+    """Decode-shaped hot path: B sequences at context S_ctx, one new token each (sequential-mode selector,
+    preallocated K/V cache passed as a strided view -- no torch.cat append as in nsa/cache/kv_cache.py:28-30)."""
+    meta, Q, Kc, K, V = make_inputs(nv, B, S_ctx, device, 7)
+    q1 = Q[:, -1:].contiguous()
+    t = S_ctx - 1
+
+    def step():
+        p_grp = nv.selection_scores(q1, Kc, meta)
+        r = nv.select_topn_ranges(p_grp[:, 0], meta, N_SEL, t)
+        return nv.selection_attention_hip(q1, K, V, r.unsqueeze(1))
+
+    ms = time_events(step, steps, warm=3)
+    return B / (ms * 1e-3), ms
+
+
+def cpu_baseline(S, seed=3):
+    """The oracle (CPU restatement of the reference path) on one full sequence of the workload."""
+    from oracle import nsa_oracle as orc
+
+    orc.build()
+    rng = np.random.default_rng(seed)
+    meta = orc.build_block_meta(S, L_CMP, D_CMP, L_SEL, N_SEL, 512)
+    S_cmp = meta.cmp_starts.size
+    Q = rng.standard_normal((1, S, G, H, D), dtype=np.float32)
+    Kc = rng.standard_normal((1, G, S_cmp, D), dtype=np.float32)
+    K = rng.standard_normal((1, G, S, D), dtype=np.float32)
+    V = rng.standard_normal((1, G, S, D), dtype=np.float32)
+    t0 = time.perf_counter()
+    p_cmp = orc.compute_pcmp_all(Q, Kc, 1.0 / 8.0)
+    _, p_grp = orc.map_pcmp_to_pslc_and_pgrp(p_cmp, meta)
+    t1 = time.perf_counter()
+    r = orc.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
+    t2 = time.perf_counter()
+    orc.sel_attention_masked(Q, K, V, r)
+    t3 = time.perf_counter()
+    return {"value": S / (t3 - t0), "unit": "tok/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"1 sequence B=1 S={S} m7c fp32, all rows: scores {t1 - t0:.2f}s select {t2 - t1:.2f}s attention {t3 - t2:.2f}s",
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--no-extra", action="store_true", help="skip the decode / 16k / 64k extras and the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import nsa_vibe_amd as nv  # fails loudly if libnsa_sel_hip.so is missing
+
+    B, S = args.batch, args.seq
+    meta, Q, Kc, K, V = make_inputs(nv, B, S, device, 1234 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hot_path(nv, meta, Q, Kc, K, V, S)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hot_path(nv, meta, Q, Kc, K, V, S)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_step = elapsed / args.steps * 1e3
+    value = world * B * S / (elapsed / args.steps)
+
+    out = {
+        "metric": "sel_branch_hot_path_prefill_tok_per_s", "value": value, "unit": "tok/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"m7c_125m selected-branch hot path (scores->top-n ranges->selection attention), one layer, "
+                               f"S={S}, B={B} per GPU, G={G} h={H} d_k=d_v={D}, l={L_CMP} d={D_CMP} l'={L_SEL} n={N_SEL}",
+                   "global_batch": world * B, "seq_len": S, "parallelism": f"batch x group shard over {world} GPU(s), no collective"},
+    }
+    if rank == 0:
+        t_sc, t_sel, t_att, Lsum, Lmean = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
+        alg_bytes = Lsum * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V counted once per group
+        achieved = alg_bytes / (t_att * 1e-3) / 1e9
+        flops = 4.0 * H * Lsum * D
+        out["roofline"] = {"kernel": "sel_attn_fwd_mfma_kernel<bf16,64>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
+                           "mfma_tflops": flops / (t_att * 1e-3) / 1e12, "mfma_frac": flops / (t_att * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att}
+        if not args.no_extra and world == 1:
+            extra = {}
+            try:
+                for Bd in (1, 64):
+                    tok_s, ms = decode_bench(nv, Bd, 65536 if Bd == 1 else 16384, 30, device)
+                    extra[f"decode_B{Bd}"] = {"tok_per_s": tok_s, "ms_per_step": ms, "context": 65536 if Bd == 1 else 16384}
+                for S2, B2 in ((4096, 1), (16384, 1), (65536, 1)):
+                    m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
+                    ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 3, warm=1)
+                    sc, se, at, Ls, Lm = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 3)
+                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "scores_ms": sc, "select_ms": se, "attention_ms": at,
+                                                    "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9, "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12}
+                    del m2, Q2, Kc2, K2, V2
+            except Exception as e:  # noqa: BLE001 -- extras must not void the headline number
+                extra["error"] = repr(e)
+            out["extra"] = extra
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
