@@ -123,11 +123,17 @@ NSA_API int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, 
                  float scale, void *stream);
 
 /* Fused scorer: Q,K_cmp -> p_grp [B,S,G,S_sel] fp32 without materialising p_cmp / p_slc.
- * workspace: nsa_sel_scores_workspace() bytes. */
+ *   l, d, l_sel: the block geometry the CSC was built for.  For l = 2d, l' = 4d (the reference default
+ *   32/16/64) and bf16/f16 inputs with Dk in {64,128}, h <= 16, a single MFMA kernel evaluates Eq.9 in
+ *   closed form; every other case runs the query-chunked generic path and needs the workspace.
+ *   causal_skip != 0: entries p_grp[b,t,g,j] of blocks the selector can never pick at t
+ *   ((j+1) l' > t+1, masked to -inf by both selectors) are returned as 0 instead of being computed.
+ *   workspace: nsa_sel_scores_workspace() bytes (0 when the MFMA kernel applies). */
 NSA_API size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int S_cmp, int S_sel);
 NSA_API int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk,
                    int S_cmp, int64_t kc_stride_b, int64_t kc_stride_g, int64_t kc_stride_s,
                    const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel,
+                   int l, int d, int l_sel, int causal_skip, int variant /* 0 auto, 1 generic, 2 MFMA */,
                    int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -39,6 +39,10 @@ size_t scores_workspace(int64_t, int, int);
 int launch_sel_scores(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t,
                       const int32_t *, const int32_t *, const float *, int, int, float, void *, size_t, hipStream_t);
 
+bool scores_mfma_supported(int, int, int, int, int, int);
+int launch_sel_scores_mfma(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t, int,
+                           int, int, float, int, hipStream_t);
+
 static bool dtype_ok(int dt) { return dt == NSA_DT_F32 || dt == NSA_DT_BF16 || dt == NSA_DT_F16; }
 
 }  // namespace nsa
@@ -251,11 +255,19 @@ size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int S_cmp, int S_sel
 
 int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp,
                    int64_t csb, int64_t csg, int64_t css, const int32_t *csc_ptr, const int32_t *csc_rows,
-                   const float *csc_vals, int S_sel, int dtype, float scale, void *workspace, size_t workspace_bytes,
-                   void *stream) {
+                   const float *csc_vals, int S_sel, int l, int d, int l_sel, int causal_skip, int variant, int dtype,
+                   float scale, void *workspace, size_t workspace_bytes, void *stream) {
     NSA_CHECK_ARG(dtype_ok(dtype), "sel_scores: unknown dtype %d", dtype);
     NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1, "sel_scores: bad sizes");
+    NSA_CHECK_ARG(variant >= 0 && variant <= 2, "sel_scores: unknown variant %d", variant);
     if (scale <= 0.f) scale = 1.0f / sqrtf((float)Dk);
+    const bool fast = scores_mfma_supported(dtype, h, Dk, l, d, l_sel) && S_cmp >= 1 && (int64_t)B * S * G > 0 && S_sel > 0 &&
+                      csb % 8 == 0 && csg % 8 == 0 && css % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K_cmp % 16 == 0) &&
+                      (int64_t)B * G <= 65535;
+    if (variant == 2) NSA_CHECK_ARG(fast, "sel_scores: MFMA variant requested but dtype/shape/geometry unsupported");
+    if (fast && variant != 1)
+        return launch_sel_scores_mfma(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, S_sel, d, dtype, scale, causal_skip,
+                                      (hipStream_t)stream);
     return launch_sel_scores(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel,
                              dtype, scale, workspace, workspace_bytes, (hipStream_t)stream);
 }

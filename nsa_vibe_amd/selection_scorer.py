@@ -112,9 +112,14 @@ def group_reduce_pslc(p_slc: torch.Tensor) -> torch.Tensor:
     return acc
 
 
-def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, scale: Optional[float] = None) -> torch.Tensor:
+def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, scale: Optional[float] = None,
+                     causal_skip: bool = False, variant: int = 0) -> torch.Tensor:
     """Fused A2+A3+A4: Q [B,S,G,h,Dk], K_cmp [B,G,S_cmp,Dk] -> p_grp [B,S,G,S_sel] fp32 without
-    materialising p_cmp (nsa_attention.py:1073-1091 in one call)."""
+    materialising p_cmp (nsa_attention.py:1073-1091 in one call).
+
+    causal_skip=True returns 0 for the blocks neither selector can pick at row t ((j+1) l' > t+1; both mask
+    them to -inf, selection_scorer.py:156,276-280) instead of computing them.  variant: 0 auto, 1 generic
+    (any dtype/geometry, query-chunked), 2 the MFMA kernel (bf16/f16, default block geometry)."""
     dev = _need_gpu(Q_all, K_cmp)
     B, S, G, h, Dk = Q_all.shape
     S_cmp, S_sel = K_cmp.shape[2], meta.S_sel
@@ -125,12 +130,16 @@ def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, 
         return p_grp
     L = _lib.lib()
     nbytes = L.nsa_sel_scores_workspace(B, S, G, h, S_cmp, S_sel) if S_cmp > 0 else 0
-    ws = workspace(dev, nbytes, "scores")
+    # the MFMA kernel needs no workspace; mirror of the eligibility test in nsa_sel_scores (csrc/nsa_api.hip)
+    fast = (variant != 1 and Q_all.dtype in (torch.bfloat16, torch.float16) and meta.l == 2 * meta.d and meta.l_sel == 4 * meta.d
+            and Dk in (64, 128) and h <= 16 and S_cmp >= 1 and B * G <= 65535 and sb % 8 == 0 and sg % 8 == 0 and ss % 8 == 0
+            and Q_all.data_ptr() % 16 == 0 and K_cmp.data_ptr() % 16 == 0)
+    ws = None if fast else workspace(dev, nbytes, "scores")
     cptr, crows, cvals = meta.device_csc(dev)
     rc = L.nsa_sel_scores(Q_all.data_ptr(), K_cmp.data_ptr(), p_grp.data_ptr(), B, S, G, h, Dk, S_cmp, sb, sg, ss,
-                          cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(), S_sel, _DT[Q_all.dtype],
-                          float(scale) if scale else 0.0, ws.data_ptr() if ws is not None else None,
-                          ws.numel() if ws is not None else 0, _stream(dev))
+                          cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(), S_sel, int(meta.l), int(meta.d), int(meta.l_sel),
+                          int(bool(causal_skip)), int(variant), _DT[Q_all.dtype], float(scale) if scale else 0.0,
+                          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
     _lib.check(rc, "nsa_sel_scores")
     return p_grp
 

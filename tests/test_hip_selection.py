@@ -157,6 +157,34 @@ def test_g11_small_chains(nv):
         assert np.abs(O.cpu().numpy() - g[f"c{ci}_O"]).max() <= 1e-3
 
 
+@pytest.mark.parametrize("S,B,h,D", [(4096, 2, 6, 64), (1000, 1, 6, 64), (1025, 1, 4, 64), (777, 2, 16, 64), (520, 1, 3, 128), (64, 1, 6, 64), (33, 2, 6, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mfma_scorer_vs_oracle(nv, orc, S, B, h, D, dtype):
+    """fused MFMA scorer (closed-form Eq.9 stencil) vs the oracle chain on the rounded inputs, 1e-6 absolute;
+    causal_skip returns exactly the same values on every block a selector can read and 0 elsewhere."""
+    rng = np.random.default_rng([S, h, D])
+    G = 2
+    m = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    mo = orc.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    Kc = rng.standard_normal((B, G, m.S_cmp, D), dtype=np.float32) * 1.5
+    rd = lambda a: torch.from_numpy(a).to(dtype).float().numpy()  # noqa: E731
+    ref = orc.map_pcmp_to_pslc_and_pgrp(orc.compute_pcmp_all(rd(Q), rd(Kc), 1.0 / np.sqrt(D)), mo)[1]
+    got = nv.selection_scores(dev(Q, dtype), dev(Kc, dtype), m, variant=2)
+    assert got.shape == ref.shape
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-6
+    gen = nv.selection_scores(dev(Q, dtype), dev(Kc, dtype), m, variant=1)
+    assert np.abs(gen.cpu().numpy() - ref).max() < 2e-6
+    skip = nv.selection_scores(dev(Q, dtype), dev(Kc, dtype), m, variant=2, causal_skip=True)
+    t = torch.arange(S, device="cuda").view(1, S, 1, 1)
+    j = torch.arange(m.S_sel, device="cuda").view(1, 1, 1, -1)
+    readable = (j + 1) * 64 <= t + 1
+    assert torch.equal(torch.where(readable, skip, 0), torch.where(readable, got, 0))
+    # ranges from the skipped scores are identical to ranges from the full scores, both modes
+    assert torch.equal(nv.select_topn_ranges_batched(skip, m, 16, S), nv.select_topn_ranges_batched(got, m, 16, S))
+    assert torch.equal(nv.select_topn_ranges_rows(skip, m, 16), nv.select_topn_ranges_rows(got, m, 16))
+
+
 def test_selector_vs_oracle_random_configs(nv, orc):
     """random (l', n_top, forced) configurations incl. wide rows (S_sel up to 2048)."""
     rng = np.random.default_rng(123)
