@@ -1,6 +1,7 @@
 // MFMA selection-attention forward for gfx950 (bf16 / f16, Dk = Dv = D in {64,128}, h <= 16).
 //
-// Mapping (one wave64 = one query row (b,t,g); a 256-thread workgroup = 4 independent rows):
+// Mapping (one wave64 = one query row (b,t,g); a 256-thread workgroup = 4 consecutive tokens of one
+// (b,g), so the forced blocks -- block 0 and the local blocks -- are shared through the CU's L1):
 //   * The h query heads of the GQA group are the 16 columns of a 16x16x32 MFMA (columns >= h are
 //     zero padding), so every K/V byte fetched is shared by all heads of the group -- K/V are read
 //     once per group, never per head (the reference's Triton kernels re-read them per head,
@@ -9,16 +10,23 @@
 //     attention_kernels.py:721-732) and walked in 32-token tiles; tail tiles are masked.
 //   * S^T[key, head] = K_tile[32 x D] . Q^T[D x 16]  : A = K rows from LDS (ds_read_b128, XOR
 //     swizzled 16-B pieces), B = Q^T fragments held in registers for the whole row.
-//   * online softmax in fp32 (exp2 domain); keys live in the accumulator registers and the 4 lane
-//     groups, so the row max needs two cross-lane steps per tile and the row sum none until the end.
+//   * softmax in fp32, exp2 domain.  Keys live in the accumulator registers and the 4 lane groups,
+//     so the row sum needs no cross-lane work until the epilogue.  The running max is only raised
+//     when a tile exceeds it by more than RESCALE_THR (log2 units): in the steady state a tile costs
+//     8 fma + 8 exp + 8 add + 4 cvt per lane and no cross-lane instruction, and the O accumulators are
+//     not touched by the VALU at all.  exp2 arguments stay <= RESCALE_THR, so p <= 256 (bf16 P, fp32 l,O).
 //   * O^T[dv, head] += V^T[dv x 32 keys] . P^T[32 keys x 16] : B = P^T taken straight from the S^T
 //     accumulators (cvt to bf16, no lane movement: the k index of the PV MFMA is mapped onto the
 //     accumulator's key order), A = V^T read with ds_read_b64_tr_b16 (hardware transpose) from a
 //     row-major, XOR-swizzled V tile.
 //   * HBM/L2 -> LDS staging is register staged with one tile of prefetch: the global loads of tile
 //     i+1 are issued before the MFMAs of tile i.  Every global load instruction covers whole 128-B
-//     (D=64) / 256-B (D=128) rows: lanes are row-linear, 16 B per lane.
+//     (D=64) / 256-B (D=128) rows (lanes row-linear, 16 B per lane; fragment-shaped K loads straight to
+//     registers measured 15-20 % slower).  Full tiles use a scalar tile base + per-lane 32-bit offsets
+//     computed once per row (no per-tile address arithmetic on the VALU).
 // All LDS is wave private: no workgroup barrier anywhere in the kernel.
+#include <stdlib.h>
+
 #include "nsa_common.hpp"
 #include "sel_attn_params.hpp"
 
@@ -63,6 +71,7 @@ struct Geo {
 };
 
 constexpr int PART_PAD = 4;  // split-KV partial record per head: m, l, 2 pad floats, then D accumulators (16-B aligned)
+constexpr float RESCALE_THR = 8.0f;  // log2 units: raise the running max only when a tile exceeds it by more than this
 
 template <typename T, int D, bool SPLIT>
 __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P) {
@@ -75,8 +84,27 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
     const int wave = uniform((int)(threadIdx.x >> 6));
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int nsplit = SPLIT ? P.nsplit : 1;
-    const int64_t row = SPLIT ? wid / nsplit : wid;
+    int64_t row = SPLIT ? wid / nsplit : wid;
     const int sp = SPLIT ? (int)(wid % nsplit) : 0;
+    if (!SPLIT && P.map_mode != 0) {
+        // workgroup = 4 consecutive tokens of ONE (b,g).  map_mode 2 (B*G % 8 == 0): workgroups are dealt
+        // round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), so give every XCD whole (b,g) pairs
+        // and walk them one after the other: the K/V of one (b,g) (1 MiB at S=4096) then stays in that XCD's
+        // 4 MiB L2.  Placement only changes speed, never results.
+        const int W = (P.S + 3) >> 2;  // workgroups per (b,g)
+        int bg, tc;
+        if (P.map_mode == 2) {
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            bg = (idx / W) * 8 + xcd;
+            tc = idx % W;
+        } else {
+            bg = blockIdx.x / W;
+            tc = blockIdx.x % W;
+        }
+        const int t = 4 * tc + wave;
+        if (t >= P.S) return;
+        row = ((int64_t)(bg / P.G) * P.S + t) * P.G + (bg % P.G);
+    }
     if (row >= P.R) return;
 
     unsigned char *kl = smem + (size_t)wave * G_::WAVE_LDS;
@@ -86,9 +114,10 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
     const int h = P.h;
     const int g = (int)(row % P.G);
     const int b = (int)(row / ((int64_t)P.G * P.S));
-    const T *Kb = (const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg;
-    const T *Vb = (const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg;
+    const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
+    const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
     const T *Qr = (const T *)P.Q + row * (int64_t)h * D;
+    const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;  // row pitch in bytes
 
     int nseg;
     const int L = normalise_ranges(P.ranges + row * (int64_t)P.n * 2, P.n, P.S_kv, seg, &nseg);
@@ -105,41 +134,85 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
         qf[s] = __builtin_bit_cast(x8, raw);
     }
 
-    // ---- tile iterator over the segments (all wave-uniform)
-    int it_seg = 0, it_pos = 0, it_cnt = 0;
+    // ---- per-lane constants: global byte offsets inside a full tile, LDS write/read offsets.  Wherever the XOR
+    // swizzle term does not depend on the unrolled index the offset is written as base + compile-time constant so
+    // it folds into the instruction's immediate offset field (one VGPR instead of one per unrolled access).
+    const int ld_row = lane / G_::PIECES;    // row within one wave-wide load
+    const int ld_piece = lane % G_::PIECES;  // 16-B piece within the row
+    const uint32_t koff0 = (uint32_t)(ld_row * krowb + ld_piece * 16);
+    const uint32_t voff0 = (uint32_t)(ld_row * vrowb + ld_piece * 16);
+    constexpr bool WR_IMM = (G_::RPI % G_::PIECES) == 0 && (G_::RPI % 8) == 0;  // swizzle of row i*RPI+ld_row == swizzle of ld_row
+    uint32_t kwr[G_::NLD], vwr[G_::NLD];
+#pragma unroll
+    for (int i = 0; i < G_::NLD; ++i) {
+        const int r = i * G_::RPI + ld_row;
+        const int rs = WR_IMM ? ld_row : r;
+        kwr[i] = i * G_::RPI * G_::ROWB + ld_row * G_::ROWB + ((ld_piece ^ G_::swz_k(rs)) << 4);
+        vwr[i] = i * G_::RPI * G_::ROWB + ld_row * G_::ROWB + ((((ld_piece >> 1) ^ G_::swz_v(rs)) << 5) | ((ld_piece & 1) << 4));
+    }
+    // reads: row 16u + rho (K) / 16u + 4q + qq (V): both swizzles are invariant under +16 rows
+    uint32_t krd0[G_::KSTEPS], vrd0[G_::MT];
+#pragma unroll
+    for (int s = 0; s < G_::KSTEPS; ++s) krd0[s] = rho * G_::ROWB + (((4 * s + q) ^ G_::swz_k(rho)) << 4);
+    {
+        const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
+#pragma unroll
+        for (int m = 0; m < G_::MT; ++m) vrd0[m] = r * G_::ROWB + ((m ^ G_::swz_v(r)) << 5) + 8 * pp;
+    }
+
+    // ---- tile iterator over the segments (all wave-uniform scalars)
+    int it_seg = -1, it_start = 0, it_len = 0, it_pos = 0, it_cnt = 0;
     auto next_tile = [&](int &tok0, int &nvalid) -> bool {
         while (true) {
-            if (it_seg >= nseg) return false;
-            const int off0 = uniform(seg[2 * it_seg + 1]);
-            const int off1 = uniform(seg[2 * it_seg + 3]);
-            const int len = off1 - off0;
-            if (it_pos >= len) {
-                ++it_seg;
-                it_pos = 0;
-                continue;
+            if (it_pos < it_len) {
+                tok0 = it_start + it_pos;
+                nvalid = min(32, it_len - it_pos);
+                it_pos += 32;
+                if (SPLIT) {
+                    const bool mine = (it_cnt % nsplit) == sp;
+                    ++it_cnt;
+                    if (!mine) continue;
+                }
+                return true;
             }
-            tok0 = uniform(seg[2 * it_seg]) + it_pos;
-            nvalid = min(32, len - it_pos);
-            it_pos += 32;
-            if (SPLIT) {
-                const bool mine = (it_cnt % nsplit) == sp;
-                ++it_cnt;
-                if (!mine) continue;
-            }
-            return true;
+            if (++it_seg >= nseg) return false;
+            it_start = uniform(seg[2 * it_seg]);
+            it_len = uniform(seg[2 * it_seg + 3]) - uniform(seg[2 * it_seg + 1]);
+            it_pos = 0;
         }
     };
 
-    const int ld_row = lane / G_::PIECES;    // row within one wave-wide load
-    const int ld_piece = lane % G_::PIECES;  // 16-B piece within the row
+    // K/V of this (b,g) as buffer resources: loads are `buffer_load_dwordx4 v, voffset(VGPR), srsrc, soffset(SGPR)` --
+    // the per-tile part of the address is scalar, the per-lane part a loop-invariant VGPR: no VALU address math.
+    // The descriptor is built from wave-uniform values only (readfirstlane'd halves), so no waterfall loop is emitted.
+    typedef __attribute__((ext_vector_type(4))) unsigned int bu32x4;
+    auto make_rsrc = [&](const unsigned char *base, int64_t bytes) {
+        const uint64_t a = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + G_::ROWB);
+    const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + G_::ROWB);
+    // readfirstlane pins these in SGPRs (a soffset the compiler keeps in a VGPR costs a waterfall loop per load)
+    const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    const int kstep = uniform(G_::RPI * (int)krowb), vstep = uniform(G_::RPI * (int)vrowb);
     u32x4 kreg[G_::NLD], vreg[G_::NLD];
     auto issue_loads = [&](int tok0, int nvalid) {
+        const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);  // scalar byte offsets of the tile
+        if (nvalid == 32) {
 #pragma unroll
-        for (int i = 0; i < G_::NLD; ++i) {
-            const int r = i * G_::RPI + ld_row;
-            const int64_t t = tok0 + min(r, nvalid - 1);
-            kreg[i] = *(const u32x4 *)(Kb + t * P.kss + ld_piece * 8);
-            vreg[i] = *(const u32x4 *)(Vb + t * P.vss + ld_piece * 8);
+            for (int i = 0; i < G_::NLD; ++i) {
+                kreg[i] = __builtin_bit_cast(u32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(krs, koff0, ks + i * kstep, 0));
+                vreg[i] = __builtin_bit_cast(u32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(vrs, voff0, vs + i * vstep, 0));
+            }
+        } else {  // tail tile: clamp the row so nothing outside the segment is touched
+#pragma unroll
+            for (int i = 0; i < G_::NLD; ++i) {
+                const int r = min(i * G_::RPI + ld_row, nvalid - 1);
+                kreg[i] = __builtin_bit_cast(u32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(krs, r * krowb32 + ld_piece * 16, ks, 0));
+                vreg[i] = __builtin_bit_cast(u32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(vrs, r * vrowb32 + ld_piece * 16, vs, 0));
+            }
         }
     };
 
@@ -158,9 +231,8 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
         // ---- stage registers -> LDS (swizzled)
 #pragma unroll
         for (int i = 0; i < G_::NLD; ++i) {
-            const int r = i * G_::RPI + ld_row;
-            *(u32x4 *)(kl + r * G_::ROWB + ((ld_piece ^ G_::swz_k(r)) << 4)) = kreg[i];
-            *(u32x4 *)(vl + r * G_::ROWB + ((((ld_piece >> 1) ^ G_::swz_v(r)) << 5) | ((ld_piece & 1) << 4))) = vreg[i];
+            *(u32x4 *)(kl + kwr[i]) = kreg[i];
+            *(u32x4 *)(vl + vwr[i]) = vreg[i];
         }
         // ---- prefetch the next tile while this one is consumed
         have = next_tile(tok0, nvalid);
@@ -172,49 +244,55 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             sacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int r = 16 * u + rho;
 #pragma unroll
-            for (int s = 0; s < G_::KSTEPS; ++s) {
-                const x8 a = *(const x8 *)(kl + r * G_::ROWB + (((4 * s + q) ^ G_::swz_k(r)) << 4));
-                sacc[u] = M::mma(a, qf[s], sacc[u]);
-            }
+            for (int s = 0; s < G_::KSTEPS; ++s) sacc[u] = M::mma(*(const x8 *)(kl + krd0[s] + u * 16 * G_::ROWB), qf[s], sacc[u]);
         }
-        // ---- online softmax (exp2 domain); key of sacc[u][j] is 16u + 4q + j
+        // ---- softmax, exp2 domain, deferred max; key of sacc[u][j] is 16u + 4q + j
         float x[8];
-        float tmax = -INFINITY;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = 16 * u + 4 * q + j;
-                const float v = (key < cur_nvalid) ? sacc[u][j] * c2 : -INFINITY;
-                x[4 * u + j] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mrun, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-        mrun = mnew;
+            for (int j = 0; j < 4; ++j) x[4 * u + j] = fmaf(sacc[u][j], c2, -mrun);
+        const float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+        // slow path: the running max must be raised (always for the first tile: mrun = -inf -> x = +inf), or the
+        // tile is a masked tail tile (the mask is only applied here, the common path carries no select)
+        if (__any(!(tmax <= RESCALE_THR)) || cur_nvalid != 32) {
+            asm volatile("; slow path (keeps the compiler from if-converting it into the common path)" ::: "memory");
+            float vmax = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (16 * u + 4 * q + j < cur_nvalid) ? sacc[u][j] * c2 : -INFINITY;
+                    x[4 * u + j] = v;
+                    vmax = fmaxf(vmax, v);
+                }
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 16, 64));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+            const float mnew = fmaxf(mrun, vmax);  // finite: every tile has at least one valid key
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            mrun = mnew;
+            lrun *= alpha;
+#pragma unroll
+            for (int m = 0; m < G_::MT; ++m) o[m] *= alpha;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] -= mnew;
+        }
         float psum = 0.f;
         x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float pe = __builtin_amdgcn_exp2f(x[j] - mnew);
+            const float pe = __builtin_amdgcn_exp2f(x[j]);
             psum += pe;
             pf[j] = Elt<T>::from_f(pe);
         }
-        lrun = lrun * alpha + psum;
-#pragma unroll
-        for (int m = 0; m < G_::MT; ++m) o[m] *= alpha;
+        lrun += psum;
 
         // ---- O^T += V^T . P^T   (k index j<4 -> key 4q+j, j>=4 -> key 16+4q+(j-4))
-        const int qq = rho >> 2, pp = rho & 3;
-        const int r0 = 4 * q + qq, r1 = 16 + 4 * q + qq;
 #pragma unroll
         for (int m = 0; m < G_::MT; ++m) {
-            const x4 lo = M::tr(vl + r0 * G_::ROWB + ((m ^ G_::swz_v(r0)) << 5) + 8 * pp);
-            const x4 hi = M::tr(vl + r1 * G_::ROWB + ((m ^ G_::swz_v(r1)) << 5) + 8 * pp);
+            const x4 lo = M::tr(vl + vrd0[m]);
+            const x4 hi = M::tr(vl + vrd0[m] + 16 * G_::ROWB);
             x8 a;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -230,7 +308,7 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
     float ltot = lrun + __shfl_xor(lrun, 16, 64);
     ltot += __shfl_xor(ltot, 32, 64);
     if (SPLIT) {
-        // partial record [row][sp][head][2 + D]: m (log2 domain), l, unnormalised O
+        // partial record [row][sp][head][PART_PAD + D]: m (log2 domain), l, unnormalised O
         float *pr = P.part + ((row * nsplit + sp) * (int64_t)h + rho) * (D + PART_PAD);
         if (rho < h) {
             if (q == 0) {
@@ -312,7 +390,24 @@ static int launch_mfma_t(const SelAttnParams &P0, hipStream_t st) {
     const bool split = P.part != nullptr && P.nsplit > 1;
     if (!split) P.nsplit = 1;
     const int64_t waves = P.R * P.nsplit;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
+    unsigned grid = (unsigned)((waves + 3) / 4);
+    P.map_mode = 0;
+    if (!split && P.S >= 16) {
+        const int64_t nbg = P.R / P.S;  // B*G
+        const int64_t W = (P.S + 3) / 4;
+        if (nbg * W < (int64_t)1 << 31) {
+            P.map_mode = (nbg % 8 == 0) ? 2 : 1;
+            grid = (unsigned)(nbg * W);
+        }
+    }
+    if (const char *e = getenv("NSA_HIP_ATTN_MAP")) {  // A/B switch for measurements: force a mapping
+        const int m = atoi(e);
+        if (!split && m == 0) {
+            P.map_mode = 0;
+            grid = (unsigned)((waves + 3) / 4);
+        }
+        if (!split && m == 1 && P.map_mode == 2) P.map_mode = 1;
+    }
     auto k = split ? sel_attn_fwd_mfma_kernel<T, D, true> : sel_attn_fwd_mfma_kernel<T, D, false>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, P);
@@ -330,6 +425,8 @@ int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st) 
                   "MFMA kernel: K/V strides must be multiples of 8 elements (16 B)");
     NSA_CHECK_ARG(((uintptr_t)P.Q % 16 == 0) && ((uintptr_t)P.K % 16 == 0) && ((uintptr_t)P.V % 16 == 0) && ((uintptr_t)P.O % 8 == 0),
                   "MFMA kernel: Q/K/V must be 16-byte aligned");
+    NSA_CHECK_ARG((int64_t)P.S_kv * P.kss * 2 < ((int64_t)1 << 31) && (int64_t)P.S_kv * P.vss * 2 < ((int64_t)1 << 31),
+                  "MFMA kernel: one (b,g) K/V slab must be smaller than 2 GiB (buffer addressing)");
     if (dtype == NSA_DT_BF16) return P.Dk == 64 ? launch_mfma_t<__bf16, 64>(P, st) : launch_mfma_t<__bf16, 128>(P, st);
     return P.Dk == 64 ? launch_mfma_t<_Float16, 64>(P, st) : launch_mfma_t<_Float16, 128>(P, st);
 }

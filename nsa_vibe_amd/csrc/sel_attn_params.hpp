@@ -19,6 +19,7 @@ struct SelAttnParams {
     // split-KV (few rows): partial results, see sel_attn_mfma.hip
     float *part;  // workspace or null
     int nsplit;
+    int map_mode;  // 0 rows linear in blockIdx; 1 workgroup = 4 tokens of one (b,g); 2 = 1 + XCD-aware order
 };
 
 struct SelAttnBwdParams {

@@ -109,6 +109,26 @@ def test_mfma_random_shapes(nv, orc, h, D, dtype):
     run_case(nv, orc, Q, K, V, rg, dtype, variant=1)
 
 
+@pytest.mark.parametrize("spike_at", [0, 40, 300, 650])
+def test_mfma_deferred_max_branch(nv, orc, spike_at):
+    """The MFMA kernel raises its running max only when a tile exceeds it by > 8 (log2 units).  Force that
+    branch at a chosen tile (one K row aligned with Q, logit ~ +40 above the rest), and cases where the
+    max never grows after the first tile / grows in the last tail tile (cdna guide rule 26)."""
+    rng = np.random.default_rng(spike_at)
+    B, S, G, h, D, S_kv = 1, 4, 1, 6, 64, 700
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32) * 0.3
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    K[0, 0, spike_at] = Q[0, 0, 0, 0] * 5.0  # head 0 of row 0 gets a huge logit at this key; other heads random
+    K[0, 0, 699] = Q[0, 1, 0, 3] * 4.0  # row 1 / head 3 spikes in the masked tail tile
+    rg = np.zeros((B, S, G, 3, 2), np.int32)
+    rg[:, :, :, 0] = (0, 128)
+    rg[:, :, :, 1] = (256, 448)
+    rg[:, :, :, 2] = (600, 700)  # 100 tokens: 3 full tiles + a 4-key tail
+    run_case(nv, orc, Q, K, V, rg, torch.bfloat16, variant=2)
+    run_case(nv, orc, Q, K, V, rg, torch.float16, variant=2)
+
+
 def test_mfma_matches_generic_many_rows(nv):
     """R large enough that no split-KV is used; aligned 64-token blocks like the real selector."""
     rng = np.random.default_rng(77)
