@@ -8,9 +8,10 @@
 // duplicates, merge adjacent" a run extraction on the bitmap:
 //   * candidate key  = fp32(p) - fp32(idx) * 1e-8f, multiply and subtract rounded separately
 //     (selection_scorer.py:182-184; __fmul_rn/__fsub_rn so hipcc cannot contract to an FMA);
-//   * k picks by iterative wave arg-max on (key desc, idx asc) with xor shuffles; picking stops
-//     when only -inf keys remain (the reference then picks arbitrary -inf entries, which are
-//     either duplicates of forced blocks or future blocks it drops / emits as garbage);
+//   * the k picks are a threshold (radix) select: 32 ballot+popcount rounds find the k-th largest key,
+//     ties at the threshold go to the lowest indices = order (key desc, idx asc); -inf keys are never
+//     picked (the reference then picks arbitrary -inf entries, which are either duplicates of forced
+//     blocks or future blocks it drops / emits as garbage);
 //   * runs of the bitmap are emitted in ascending order as [start*l', min((end+1)*l', t+1)).
 #include "nsa_common.hpp"
 
@@ -76,34 +77,41 @@ __global__ __launch_bounds__(256) void select_topn_kernel(SelectParams P) {
                     }
             }
         }
-        // ---- top-k picks
-        for (int it = 0; it < P.k_actual; ++it) {
-            float bk = -INFINITY;
-            int bi = 0x7fffffff;
+        // ---- top-k picks: threshold (radix) select on an order-preserving integer image of the key.
+        // 32 rounds of {compare, ballot, popcount} find the k-th largest key T; everything above T is picked and the
+        // remaining slots go to the keys equal to T in ascending index order -- exactly (key desc, idx asc), with no
+        // cross-lane data movement (the iterative arg-max needed 12 dependent ds_bpermute per pick).
+        unsigned u[CAND];
+        int nv = 0;
 #pragma unroll
-            for (int c = 0; c < CAND; ++c)
-                if (key[c] > bk) {  // ascending c = ascending idx within the lane: strict > keeps the lowest idx
-                    bk = key[c];
-                    bi = lane + 64 * c;
-                }
+        for (int c = 0; c < CAND; ++c) {
+            const unsigned bits = __float_as_uint(key[c]);
+            const bool ok = key[c] > -INFINITY;  // forced / masked / NaN candidates never compete
+            u[c] = ok ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0u;  // valid keys map to >= 0x00800000
+            nv += __popcll(__ballot(ok));
+        }
+        const int k_eff = min(P.k_actual, nv);
+        if (k_eff > 0) {
+            unsigned T = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = T | (1u << bit);
+                int cnt = 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ok = __shfl_xor(bk, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ok > bk || (ok == bk && oi < bi)) {
-                    bk = ok;
-                    bi = oi;
-                }
+                for (int c = 0; c < CAND; ++c) cnt += __popcll(__ballot(u[c] >= cand));
+                if (cnt >= k_eff) T = cand;
             }
-            if (bk == -INFINITY) break;  // wave uniform
-            if ((bi & 63) == lane) {
-                const int c = bi >> 6;
+            int cnt_gt = 0;
 #pragma unroll
-                for (int cc = 0; cc < CAND; ++cc)
-                    if (cc == c) {
-                        key[cc] = -INFINITY;
-                        selbits |= 1u << cc;
-                    }
+            for (int c = 0; c < CAND; ++c) cnt_gt += __popcll(__ballot(u[c] > T));
+            int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
+                const bool eq = u[c] == T;
+                const unsigned long long em = __ballot(eq);
+                const int take = min(__popcll(em), remaining);
+                if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1u << c;
+                remaining -= take;
             }
         }
     }
