@@ -149,31 +149,43 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
         const int rows_valid = P.S_cmp - tile * TILE_ROWS;  // rows >= this are padding
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            float v[16];
-            float mx = -INFINITY;
+            // common path: every lane keeps its own reference max and only accumulates sum(exp2(x - m)); no max, no
+            // mask, no rescale.  All 16 exponents are <= 12 whenever the sum stays <= 2^12, so the sum itself is the
+            // test: a larger (or inf/nan: first tile, m = -inf) sum, or a padded last tile, takes the exact slow path.
+            float sum = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 16 * u + 4 * q + j;
-                    const float x = (r < rows_valid) ? acc[u][n][j] * c2 : -INFINITY;
-                    v[4 * u + j] = x;
-                    mx = fmaxf(mx, x);
-                }
-            const float mnew = fmaxf(mrun[n], mx);
-            if (mnew > -INFINITY) {  // a lane group may see only padding rows in the last tile
-                float sum = 0.f;
+                for (int j = 0; j < 4; ++j) sum += __builtin_amdgcn_exp2f(fmaf(acc[u][n][j], c2, -mrun[n]));
+            if (__any(!(sum <= 4096.f)) || rows_valid < TILE_ROWS) {
+                asm volatile("; sweep-1 slow path" ::: "memory");
+                float v[16];
+                float mx = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(v[i] - mnew);
-                lrun[n] = lrun[n] * __builtin_amdgcn_exp2f(mrun[n] - mnew) + sum;
-                mrun[n] = mnew;
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 16 * u + 4 * q + j;
+                        const float x = (r < rows_valid) ? acc[u][n][j] * c2 : -INFINITY;
+                        v[4 * u + j] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                const float mnew = fmaxf(mrun[n], mx);
+                sum = 0.f;
+                if (mnew > -INFINITY) {  // a lane group may see only padding rows in the last tile
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(v[i] - mnew);
+                    lrun[n] = lrun[n] * __builtin_amdgcn_exp2f(mrun[n] - mnew);
+                    mrun[n] = mnew;
+                }
             }
+            lrun[n] += sum;
         }
         if (tile + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
     // merge the 4 lane groups of each column
-    float mfin[NT], inv[NT];
+    float mlog[NT];  // m + log2(l): p = exp2(s*c2 - mlog)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         float m = fmaxf(mrun[n], __shfl_xor(mrun[n], 16, 64));
@@ -181,8 +193,7 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
         float l = (mrun[n] > -INFINITY) ? lrun[n] * __builtin_amdgcn_exp2f(mrun[n] - m) : 0.f;
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        mfin[n] = m;
-        inv[n] = 1.0f / l;
+        mlog[n] = m + __builtin_amdgcn_logf(l);
     }
 
     // ================= sweep 2: normalise, Eq.9 stencil, Eq.10 head sum, store =================
@@ -214,22 +225,28 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
             for (int n = 0; n < NT; ++n) {
                 float p[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int r = 16 * u + 4 * q + k;
-                    p[k] = (r < rows_valid) ? __builtin_amdgcn_exp2f(acc[u][n][k] * c2 - mfin[n]) * inv[n] : 0.f;
+                for (int k = 0; k < 4; ++k) p[k] = __builtin_amdgcn_exp2f(fmaf(acc[u][n][k], c2, -mlog[n]));
+                if (rows_valid < TILE_ROWS) {  // padded last tile only (wave uniform)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (16 * u + 4 * q + k >= rows_valid) p[k] = 0.f;
                 }
                 // 1/2 p[4j-1]: register 3 of the previous lane group (previous sub-tile for q == 0)
                 const float rot = __shfl(p[3], (lane + 48) & 63, 64);
                 const float tapm1 = (q == 0) ? rot_prev[n] : rot;
                 rot_prev[n] = rot;
-                float slc = __fmul_rn(0.5f, tapm1);
-                slc = __fadd_rn(slc, p[0]);
-                slc = __fadd_rn(slc, p[1]);
-                slc = __fadd_rn(slc, p[2]);
-                slc = __fadd_rn(slc, __fmul_rn(0.5f, p[3]));
-                // Eq.10: heads of one query are h consecutive lanes of the 16-lane row, ascending h
+                float slc = fmaf(0.5f, tapm1, p[0]);
+                slc += p[1];
+                slc += p[2];
+                slc = fmaf(0.5f, p[3], slc);
+                // Eq.10: heads of one query are h consecutive lanes of the 16-lane row; ascending-h sum with DPP row
+                // shifts (lane i reads lane i+k of its row), no LDS crossbar traffic
                 float grp = slc;
-                for (int k = 1; k < h; ++k) grp = __fadd_rn(grp, __shfl_down(slc, k, 16));
+#define NSA_HS(K) \
+    if (K < h) grp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, slc), 0x100 | K, 0xf, 0xf, true));
+                NSA_HS(1) NSA_HS(2) NSA_HS(3) NSA_HS(4) NSA_HS(5) NSA_HS(6) NSA_HS(7) NSA_HS(8)
+                NSA_HS(9) NSA_HS(10) NSA_HS(11) NSA_HS(12) NSA_HS(13) NSA_HS(14) NSA_HS(15)
+#undef NSA_HS
                 if (tq[n] >= 0 && (rho % h) == 0 && j <= jlast)
                     P.p_grp[(((int64_t)b * P.S + tq[n]) * P.G + g) * (int64_t)P.S_sel + j] = grp;
             }
