@@ -128,12 +128,16 @@ NSA_API int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, 
  *   closed form; every other case runs the query-chunked generic path and needs the workspace.
  *   causal_skip != 0: entries p_grp[b,t,g,j] of blocks the selector can never pick at t
  *   ((j+1) l' > t+1, masked to -inf by both selectors) are returned as 0 instead of being computed.
- *   workspace: nsa_sel_scores_workspace() bytes (0 when the MFMA kernel applies). */
-NSA_API size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int S_cmp, int S_sel);
+ *   Few query rows (B*S*G <= 1024: decode) run a decode-shaped pair of kernels that spreads the K_cmp sweep of a
+ *   row over many workgroups (any dtype / geometry); it needs B*S*G*h*S_cmp floats of workspace.
+ *   variant: 0 auto, 1 generic, 2 MFMA (prefill), 3 decode-shaped.
+ *   workspace: nsa_sel_scores_workspace(same shape/geometry/dtype/variant) bytes (0 for the MFMA route). */
+NSA_API size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int Dk, int S_cmp, int S_sel, int l, int d, int l_sel,
+                                int dtype, int variant);
 NSA_API int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk,
                    int S_cmp, int64_t kc_stride_b, int64_t kc_stride_g, int64_t kc_stride_s,
                    const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel,
-                   int l, int d, int l_sel, int causal_skip, int variant /* 0 auto, 1 generic, 2 MFMA */,
+                   int l, int d, int l_sel, int causal_skip, int variant /* 0 auto, 1 generic, 2 MFMA, 3 decode */,
                    int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ SIGNATURES = {
     "nsa_build_block_meta_host": (_i, [_i] * 4 + [_vp] * 6),
     "nsa_map_pcmp_to_pgrp": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "nsa_pcmp_all": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_i, _f, _vp]),
-    "nsa_sel_scores_workspace": (_sz, [_i] * 6),
+    "nsa_sel_scores_workspace": (_sz, [_i] * 12),
     "nsa_sel_scores": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_vp, _vp, _vp] + [_i] * 7 + [_f, _vp, _sz, _vp]),
     "nsa_batched_ranges_width": (_i, [_i] * 6),
     "nsa_select_topn_ranges": (_i, [_vp, _i64, _i, _i, _i, _vp] + [_i] * 7 + [_vp, _i, _vp]),

@@ -39,6 +39,10 @@ size_t scores_workspace(int64_t, int, int);
 int launch_sel_scores(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t,
                       const int32_t *, const int32_t *, const float *, int, int, float, void *, size_t, hipStream_t);
 
+constexpr int64_t DECODE_MAX_ROWS = 1024;  // rows (B*S*G) up to which the decode-shaped scorer is used
+size_t decode_scores_workspace(int64_t, int, int);
+int launch_decode_scores(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t,
+                         const int32_t *, const int32_t *, const float *, int, int, float, void *, size_t, hipStream_t);
 bool scores_mfma_supported(int, int, int, int, int, int);
 int launch_sel_scores_mfma(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t, int,
                            int, int, float, int, hipStream_t);
@@ -248,9 +252,23 @@ int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, int S, i
                        (hipStream_t)stream);
 }
 
-size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int S_cmp, int S_sel) {
-    (void)S_sel;
-    return scores_workspace((int64_t)B * S * G, h, S_cmp);
+// route of nsa_sel_scores for (shape, dtype, geometry, variant): 1 generic, 2 MFMA (prefill), 3 decode-shaped
+static int scores_route(int B, int S, int G, int h, int Dk, int S_cmp, int S_sel, int l, int d, int l_sel, int dtype, int variant) {
+    const int64_t R = (int64_t)B * S * G;
+    if (variant != 0) return variant;
+    if (R > 0 && S_cmp >= 1 && S_sel > 0 && R <= DECODE_MAX_ROWS && h <= 64 && (size_t)h * Dk * 4 <= 64 * 1024) return 3;
+    if (scores_mfma_supported(dtype, h, Dk, l, d, l_sel) && S_cmp >= 1 && R > 0 && S_sel > 0 && (int64_t)B * G <= 65535) return 2;
+    return 1;
+}
+
+size_t nsa_sel_scores_workspace(int B, int S, int G, int h, int Dk, int S_cmp, int S_sel, int l, int d, int l_sel, int dtype,
+                                int variant) {
+    const int64_t R = (int64_t)B * S * G;
+    switch (scores_route(B, S, G, h, Dk, S_cmp, S_sel, l, d, l_sel, dtype, variant)) {
+        case 2: return 0;
+        case 3: return decode_scores_workspace(R, h, S_cmp);
+        default: return S_cmp > 0 ? scores_workspace(R, h, S_cmp) : 0;
+    }
 }
 
 int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp,
@@ -259,15 +277,21 @@ int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S,
                    float scale, void *workspace, size_t workspace_bytes, void *stream) {
     NSA_CHECK_ARG(dtype_ok(dtype), "sel_scores: unknown dtype %d", dtype);
     NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1, "sel_scores: bad sizes");
-    NSA_CHECK_ARG(variant >= 0 && variant <= 2, "sel_scores: unknown variant %d", variant);
+    NSA_CHECK_ARG(variant >= 0 && variant <= 3, "sel_scores: unknown variant %d", variant);
     if (scale <= 0.f) scale = 1.0f / sqrtf((float)Dk);
-    const bool fast = scores_mfma_supported(dtype, h, Dk, l, d, l_sel) && S_cmp >= 1 && (int64_t)B * S * G > 0 && S_sel > 0 &&
-                      csb % 8 == 0 && csg % 8 == 0 && css % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K_cmp % 16 == 0) &&
-                      (int64_t)B * G <= 65535;
-    if (variant == 2) NSA_CHECK_ARG(fast, "sel_scores: MFMA variant requested but dtype/shape/geometry unsupported");
-    if (fast && variant != 1)
+    const int route = scores_route(B, S, G, h, Dk, S_cmp, S_sel, l, d, l_sel, dtype, variant);
+    if (route == 3 && S_cmp >= 1 && (int64_t)B * S * G > 0 && S_sel > 0)
+        return launch_decode_scores(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel, dtype,
+                                    scale, workspace, workspace_bytes, (hipStream_t)stream);
+    if (route == 2) {
+        const bool ok = scores_mfma_supported(dtype, h, Dk, l, d, l_sel) && S_cmp >= 1 && (int64_t)B * S * G > 0 && S_sel > 0 &&
+                        csb % 8 == 0 && csg % 8 == 0 && css % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K_cmp % 16 == 0) &&
+                        (int64_t)B * G <= 65535;
+        NSA_CHECK_ARG(ok, "sel_scores: MFMA route needs bf16/f16, Dk in {64,128}, h <= 16, l = 2d, l' = 4d and 16-byte aligned rows "
+                          "(pass variant 1 for the generic route)");
         return launch_sel_scores_mfma(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, S_sel, d, dtype, scale, causal_skip,
                                       (hipStream_t)stream);
+    }
     return launch_sel_scores(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel,
                              dtype, scale, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -405,33 +405,42 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
     }
 }
 
-// combine split-KV partials: one wave per row, lane = dv
+// combine split-KV partials: one wave per (row, head); the nsplit (m,l) records are read by nsplit lanes at once
+// and the accumulators by all lanes with every split's load in flight together (no dependent-load chain)
 template <typename T, int D>
 __global__ __launch_bounds__(256) void sel_attn_combine_kernel(SelAttnParams P) {
     const int lane = lane_id();
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= P.R) return;
-    const int h = P.h, ns = P.nsplit;
-    for (int hh = 0; hh < h; ++hh) {
-        float mmax = -INFINITY;
-        for (int s = 0; s < ns; ++s) mmax = fmaxf(mmax, P.part[((row * ns + s) * (int64_t)h + hh) * (D + PART_PAD)]);
-        float ltot = 0.f;
-        float acc[D / 64];
-#pragma unroll
-        for (int c = 0; c < D / 64; ++c) acc[c] = 0.f;
-        for (int s = 0; s < ns; ++s) {
-            const float *pr = P.part + ((row * ns + s) * (int64_t)h + hh) * (D + PART_PAD);
-            const float w = (pr[0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(pr[0] - mmax);
-            ltot += pr[1] * w;
-#pragma unroll
-            for (int c = 0; c < D / 64; ++c) acc[c] += pr[PART_PAD + c * 64 + lane] * w;
-        }
-        const float inv = (ltot > 0.f) ? 1.f / ltot : 0.f;
-        T *Or = (T *)P.O + (row * (int64_t)h + hh) * D;
-#pragma unroll
-        for (int c = 0; c < D / 64; ++c) Or[c * 64 + lane] = Elt<T>::from_f(acc[c] * inv);
-        if (P.lse && lane == 0) P.lse[row * h + hh] = (ltot > 0.f) ? (mmax + __builtin_amdgcn_logf(ltot)) * LN2 : -INFINITY;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int h = P.h, ns = P.nsplit;  // ns <= 16
+    if (wid >= P.R * h) return;
+    const int64_t row = wid / h;
+    const int hh = (int)(wid % h);
+    const float *base = P.part + ((row * ns) * (int64_t)h + hh) * (D + PART_PAD);
+    const int64_t sstride = (int64_t)h * (D + PART_PAD);  // floats between consecutive splits of this (row, head)
+    float m = -INFINITY, l = 0.f;
+    if (lane < ns) {
+        m = base[lane * sstride];
+        l = base[lane * sstride + 1];
     }
+    const float mmax = wave_max(m);
+    const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mmax);
+    const float ltot = wave_sum(l * w);
+    float acc[D / 64];
+#pragma unroll
+    for (int c = 0; c < D / 64; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s < ns) {
+            const float ws = __shfl(w, s, 64);
+#pragma unroll
+            for (int c = 0; c < D / 64; ++c) acc[c] = fmaf(base[s * sstride + PART_PAD + c * 64 + lane], ws, acc[c]);
+        }
+    }
+    const float inv = (ltot > 0.f) ? 1.f / ltot : 0.f;
+    T *Or = (T *)P.O + (row * (int64_t)h + hh) * D;
+#pragma unroll
+    for (int c = 0; c < D / 64; ++c) Or[c * 64 + lane] = Elt<T>::from_f(acc[c] * inv);
+    if (P.lse && lane == 0) P.lse[row * h + hh] = (ltot > 0.f) ? (mmax + __builtin_amdgcn_logf(ltot)) * LN2 : -INFINITY;
 }
 
 // ---- host side ----------------------------------------------------------------------------
@@ -490,7 +499,7 @@ static int launch_mfma_t(const SelAttnParams &P0, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, P);
     NSA_LAUNCH_CHECK("sel_attn_fwd_mfma");
     if (split) {
-        hipLaunchKernelGGL((sel_attn_combine_kernel<T, D>), dim3((unsigned)((P.R + 3) / 4)), dim3(256), 0, st, P);
+        hipLaunchKernelGGL((sel_attn_combine_kernel<T, D>), dim3((unsigned)((P.R * P.h + 3) / 4)), dim3(256), 0, st, P);
         NSA_LAUNCH_CHECK("sel_attn_combine");
     }
     return NSA_OK;

@@ -7,6 +7,8 @@
 // CPU result bit for bit -- per (row, head, selection block) it accumulates p_cmp[r]*w over the CSC
 // list in ascending compressed row r, product and sum rounded separately (the order in which the
 // CPU scatter_add visits the COO entries), then sums the heads in ascending h.
+#include <type_traits>
+
 #include "nsa_common.hpp"
 
 namespace nsa {
@@ -124,6 +126,231 @@ int launch_pcmp(const void *Q, const void *Kc, float *p_cmp, int64_t row0, int64
         default: NSA_CHECK_ARG(false, "pcmp: unknown dtype %d", dtype);
     }
     NSA_LAUNCH_CHECK("pcmp");
+    return NSA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode-shaped scorer (few query rows, long context): the work per row is one 512-KiB sweep over
+// K_cmp at 64k, so it is spread over S_cmp/256 workgroups instead of one workgroup per (b,g):
+//   kernel 1: thread = compressed row; logits of all h heads (log2 domain) -> workspace [R,h,S_cmp]
+//   kernel 2: workgroup = query row; per-head max / sum, then per selection block the CSC taps are
+//             normalised, weighted and summed over heads (any block geometry) -> p_grp [R,S_sel]
+// ---------------------------------------------------------------------------------------
+struct DecodeParams {
+    const void *Q;   // [R,h,Dk]
+    const void *Kc;  // strided
+    float *x;        // [R,h,S_cmp] logits * scale * log2(e)
+    float *part;     // [R,h,nchunk,2] per 64-row chunk: max, sum exp2(x - max)
+    float *p_grp;    // [R,S_sel]
+    const int32_t *csc_ptr, *csc_rows;
+    const float *csc_vals;
+    int64_t R;
+    int S, G, h, Dk, S_cmp, S_sel;
+    int64_t csb, csg, css;
+    float c2;
+};
+
+constexpr int DEC_HMAX = 16;
+
+__host__ __device__ inline int dec_nchunk(int S_cmp) { return (S_cmp + 63) / 64; }
+
+// kernel 1: one wave per 64 compressed rows of one query row.  lane = compressed row (its K_cmp row is read with
+// 16-byte loads), all heads of the group at once; the wave also leaves the chunk's (max, sum exp2) per head so
+// kernel 2 never has to sweep the logits for the softmax statistics.
+template <typename T>
+__global__ __launch_bounds__(64) void decode_logits_kernel(DecodeParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = (float *)smem;  // [h][Dk]
+    constexpr int EPV = 16 / sizeof(T);  // elements per 16-byte load
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.y;
+    const int chunk = blockIdx.x, nchunk = dec_nchunk(P.S_cmp);
+    const int g = (int)(row % P.G);
+    const int b = (int)(row / ((int64_t)P.G * P.S));
+    const T *q = (const T *)P.Q + row * (int64_t)P.h * P.Dk;
+    for (int i = lane; i < P.h * P.Dk; i += 64) qs[i] = Elt<T>::to_f(q[i]);
+    wave_lds_fence();
+    const int c = chunk * 64 + lane;
+    const bool valid = c < P.S_cmp;
+    const T *kr = (const T *)P.Kc + (int64_t)b * P.csb + (int64_t)g * P.csg + (int64_t)(valid ? c : P.S_cmp - 1) * P.css;
+    const bool vec = (P.Dk % EPV == 0) && (((uintptr_t)kr & 15) == 0) && ((P.css * sizeof(T)) % 16 == 0);
+    for (int h0 = 0; h0 < P.h; h0 += DEC_HMAX) {
+        const int hc = min(DEC_HMAX, P.h - h0);
+        float acc[DEC_HMAX];
+#pragma unroll
+        for (int i = 0; i < DEC_HMAX; ++i) acc[i] = 0.f;
+        if (vec) {
+            for (int e0 = 0; e0 < P.Dk; e0 += EPV) {
+                const u32x4 raw = *(const u32x4 *)(kr + e0);
+                const T *kv = (const T *)&raw;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) {
+                    const float kf = Elt<T>::to_f(kv[j]);
+#pragma unroll
+                    for (int i = 0; i < DEC_HMAX; ++i)
+                        if (i < hc) acc[i] = fmaf(qs[(h0 + i) * P.Dk + e0 + j], kf, acc[i]);
+                }
+            }
+        } else {
+            for (int e = 0; e < P.Dk; ++e) {
+                const float kf = Elt<T>::to_f(kr[e]);
+#pragma unroll
+                for (int i = 0; i < DEC_HMAX; ++i)
+                    if (i < hc) acc[i] = fmaf(qs[(h0 + i) * P.Dk + e], kf, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DEC_HMAX; ++i)
+            if (i < hc) {
+                const float x = acc[i] * P.c2;
+                if (valid) P.x[(row * P.h + h0 + i) * (int64_t)P.S_cmp + c] = x;
+                const float m = wave_max(valid ? x : -INFINITY);
+                const float l = wave_sum(valid ? __builtin_amdgcn_exp2f(x - m) : 0.f);
+                if (lane == 0) {
+                    float *pr = P.part + ((row * P.h + h0 + i) * (int64_t)nchunk + chunk) * 2;
+                    pr[0] = m;
+                    pr[1] = l;
+                }
+            }
+    }
+}
+
+// kernel 1, MFMA form (bf16/f16, Dk % 32 == 0, h <= 16): the 64 compressed rows of the chunk are the MFMA rows,
+// the h heads the 16 columns; K_cmp fragments are loaded straight into the A-operand layout (one pass, no reuse).
+template <typename T, int KSTEPS>
+__global__ __launch_bounds__(64) void decode_logits_mfma_kernel(DecodeParams P) {
+    typedef typename std::conditional<std::is_same<T, __bf16>::value, bf16x8, f16x8>::type x8;
+    const int lane = threadIdx.x, rho = lane & 15, q = lane >> 4;
+    const int64_t row = blockIdx.y;
+    const int chunk = blockIdx.x, nchunk = dec_nchunk(P.S_cmp);
+    const int g = (int)(row % P.G);
+    const int b = (int)(row / ((int64_t)P.G * P.S));
+    const int Dk = 32 * KSTEPS;
+    x8 qf[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        u32x4 raw = {0u, 0u, 0u, 0u};
+        if (rho < P.h) raw = *(const u32x4 *)((const T *)P.Q + (row * P.h + rho) * (int64_t)Dk + 32 * s + 8 * q);
+        qf[s] = __builtin_bit_cast(x8, raw);
+    }
+    const T *kb = (const T *)P.Kc + (int64_t)b * P.csb + (int64_t)g * P.csg;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = min(chunk * 64 + 16 * u + rho, P.S_cmp - 1);
+        acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const x8 a = *(const x8 *)(kb + (int64_t)c * P.css + 32 * s + 8 * q);
+            if constexpr (std::is_same<T, __bf16>::value) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[s], acc[u], 0, 0, 0);
+            else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[s], acc[u], 0, 0, 0);
+        }
+    }
+    // lane (head rho, group q) holds rows 16u + 4q + j of the chunk
+    float m = -INFINITY;
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = chunk * 64 + 16 * u + 4 * q + j;
+            const float v = acc[u][j] * P.c2;
+            x[4 * u + j] = v;
+            if (c < P.S_cmp) {
+                if (rho < P.h) P.x[(row * P.h + rho) * (int64_t)P.S_cmp + c] = v;
+                m = fmaxf(m, v);
+            }
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (chunk * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(x[4 * u + j] - m);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q == 0 && rho < P.h) {
+        float *pr = P.part + ((row * P.h + rho) * (int64_t)nchunk + chunk) * 2;
+        pr[0] = m;
+        pr[1] = l;
+    }
+}
+
+// kernel 2: one wave per 64 selection blocks of one query row: merge the chunk statistics per head (cheap, redone by
+// every wave of the row), then lane = selection block: gather the CSC taps (normalised on the fly), weight, sum over
+// heads in ascending h.
+__global__ __launch_bounds__(64) void decode_pgrp_kernel(DecodeParams P) {
+    __shared__ float mlog_s[64];
+    const int64_t row = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int nchunk = dec_nchunk(P.S_cmp);
+    for (int hh = 0; hh < P.h; ++hh) {  // h <= 64
+        const float *pr = P.part + (row * P.h + hh) * (int64_t)nchunk * 2;
+        float m = -INFINITY;
+        for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, pr[2 * c]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int c = lane; c < nchunk; c += 64) l += pr[2 * c + 1] * __builtin_amdgcn_exp2f(pr[2 * c] - m);
+        l = wave_sum(l);
+        if (lane == 0) mlog_s[hh] = m + __builtin_amdgcn_logf(l);
+    }
+    wave_lds_fence();
+    const int j = blockIdx.x * 64 + lane;
+    if (j >= P.S_sel) return;
+    const int k0 = P.csc_ptr[j], k1 = P.csc_ptr[j + 1];
+    float grp = 0.f;
+    for (int hh = 0; hh < P.h; ++hh) {
+        const float *x = P.x + (row * P.h + hh) * (int64_t)P.S_cmp;
+        const float ml = mlog_s[hh];
+        float acc = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const int r = P.csc_rows[k];
+            if (r < P.S_cmp) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[r] - ml), P.csc_vals[k]));
+        }
+        grp = __fadd_rn(grp, acc);
+    }
+    P.p_grp[row * (int64_t)P.S_sel + j] = grp;
+}
+
+size_t decode_scores_workspace(int64_t R, int h, int S_cmp) {
+    const size_t sc = (size_t)(S_cmp > 0 ? S_cmp : 1);
+    return sizeof(float) * (size_t)R * h * (sc + 2 * (size_t)dec_nchunk((int)sc));
+}
+
+int launch_decode_scores(const void *Q, const void *Kc, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp, int64_t csb,
+                         int64_t csg, int64_t css, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
+                         int S_sel, int dtype, float scale, void *ws, size_t ws_bytes, hipStream_t st) {
+    const int64_t R = (int64_t)B * S * G;
+    NSA_CHECK_ARG(h <= 64 && Dk >= 1 && (size_t)h * Dk * 4 <= 64 * 1024, "decode scorer: h/Dk too large");
+    NSA_CHECK_ARG(ws && ws_bytes >= decode_scores_workspace(R, h, S_cmp), "decode scorer: workspace too small");
+    NSA_CHECK_ARG(R <= 65535, "decode scorer: too many rows");
+    DecodeParams P{Q, Kc, (float *)ws, (float *)ws + (size_t)R * h * S_cmp, p_grp, csc_ptr, csc_rows, csc_vals, R, S, G, h, Dk, S_cmp,
+                   S_sel, csb, csg, css, scale * LOG2E};
+    const dim3 grid1((unsigned)dec_nchunk(S_cmp), (unsigned)R);
+    const size_t lds = sizeof(float) * (size_t)h * Dk;
+    const bool mfma = (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && (Dk == 64 || Dk == 128) && h <= 16 && css % 8 == 0 &&
+                      csb % 8 == 0 && csg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)Kc % 16 == 0);
+    if (mfma) {
+        if (dtype == NSA_DT_BF16) {
+            if (Dk == 64) hipLaunchKernelGGL((decode_logits_mfma_kernel<__bf16, 2>), grid1, dim3(64), 0, st, P);
+            else hipLaunchKernelGGL((decode_logits_mfma_kernel<__bf16, 4>), grid1, dim3(64), 0, st, P);
+        } else {
+            if (Dk == 64) hipLaunchKernelGGL((decode_logits_mfma_kernel<_Float16, 2>), grid1, dim3(64), 0, st, P);
+            else hipLaunchKernelGGL((decode_logits_mfma_kernel<_Float16, 4>), grid1, dim3(64), 0, st, P);
+        }
+    } else {
+        switch (dtype) {
+            case NSA_DT_F32: hipLaunchKernelGGL(decode_logits_kernel<float>, grid1, dim3(64), lds, st, P); break;
+            case NSA_DT_BF16: hipLaunchKernelGGL(decode_logits_kernel<__bf16>, grid1, dim3(64), lds, st, P); break;
+            case NSA_DT_F16: hipLaunchKernelGGL(decode_logits_kernel<_Float16>, grid1, dim3(64), lds, st, P); break;
+            default: NSA_CHECK_ARG(false, "decode scorer: unknown dtype %d", dtype);
+        }
+    }
+    NSA_LAUNCH_CHECK("decode_logits");
+    hipLaunchKernelGGL(decode_pgrp_kernel, dim3((unsigned)((S_sel + 63) / 64), (unsigned)R), dim3(64), 0, st, P);
+    NSA_LAUNCH_CHECK("decode_pgrp");
     return NSA_OK;
 }
 

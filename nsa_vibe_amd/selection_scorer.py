@@ -129,12 +129,11 @@ def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, 
     if p_grp.numel() == 0:
         return p_grp
     L = _lib.lib()
-    nbytes = L.nsa_sel_scores_workspace(B, S, G, h, S_cmp, S_sel) if S_cmp > 0 else 0
-    # the MFMA kernel needs no workspace; mirror of the eligibility test in nsa_sel_scores (csrc/nsa_api.hip)
-    fast = (variant != 1 and Q_all.dtype in (torch.bfloat16, torch.float16) and meta.l == 2 * meta.d and meta.l_sel == 4 * meta.d
-            and Dk in (64, 128) and h <= 16 and S_cmp >= 1 and B * G <= 65535 and sb % 8 == 0 and sg % 8 == 0 and ss % 8 == 0
-            and Q_all.data_ptr() % 16 == 0 and K_cmp.data_ptr() % 16 == 0)
-    ws = None if fast else workspace(dev, nbytes, "scores")
+    if variant == 0 and B * S * G > 1024 and not (sb % 8 == 0 and sg % 8 == 0 and ss % 8 == 0 and K_cmp.data_ptr() % 16 == 0):
+        variant = 1  # rows not 16-byte aligned: the MFMA route would refuse them
+    nbytes = L.nsa_sel_scores_workspace(B, S, G, h, Dk, S_cmp, S_sel, int(meta.l), int(meta.d), int(meta.l_sel), _DT[Q_all.dtype],
+                                        int(variant))
+    ws = workspace(dev, nbytes, "scores")
     cptr, crows, cvals = meta.device_csc(dev)
     rc = L.nsa_sel_scores(Q_all.data_ptr(), K_cmp.data_ptr(), p_grp.data_ptr(), B, S, G, h, Dk, S_cmp, sb, sg, ss,
                           cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(), S_sel, int(meta.l), int(meta.d), int(meta.l_sel),

@@ -185,6 +185,35 @@ def test_mfma_scorer_vs_oracle(nv, orc, S, B, h, D, dtype):
     assert torch.equal(nv.select_topn_ranges_rows(skip, m, 16), nv.select_topn_ranges_rows(got, m, 16))
 
 
+@pytest.mark.parametrize("S_ctx,B,h,D,geom", [(65536, 1, 6, 64, (32, 16, 64)), (4096, 3, 6, 64, (32, 16, 64)), (1000, 2, 4, 32, (16, 8, 32)),
+                                              (300, 2, 5, 24, (8, 4, 16)), (40, 1, 6, 64, (32, 16, 64)), (20, 1, 2, 16, (32, 16, 64))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_decode_scorer_vs_oracle(nv, orc, S_ctx, B, h, D, geom, dtype):
+    """decode-shaped scorer (one query row per (b,g), any dtype / block geometry) vs the oracle chain; then the
+    whole decode step scores -> sequential ranges -> attention against the oracle."""
+    rng = np.random.default_rng([S_ctx, h, D])
+    G = 2
+    l, d, ls = geom
+    m = nv.build_block_meta(S_ctx, l, d, ls, 16, 512)
+    mo = orc.build_block_meta(S_ctx, l, d, ls, 16, 512)
+    Q = rng.standard_normal((B, 1, G, h, D), dtype=np.float32)
+    Kc = rng.standard_normal((B, G, m.S_cmp, D), dtype=np.float32)
+    rd = lambda a: torch.from_numpy(a).to(dtype).float().numpy()  # noqa: E731
+    got = nv.selection_scores(dev(Q, dtype), dev(Kc, dtype), m, variant=3)
+    assert got.shape == (B, 1, G, m.S_sel)
+    if m.S_cmp == 0:
+        assert not got.any()
+        return
+    ref = orc.map_pcmp_to_pslc_and_pgrp(orc.compute_pcmp_all(rd(Q), rd(Kc), 1.0 / np.sqrt(D)), mo)[1]
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-6
+    auto = nv.selection_scores(dev(Q, dtype), dev(Kc, dtype), m)  # auto route = decode-shaped for few rows
+    assert torch.equal(auto, got)
+    t = S_ctx - 1
+    r = nv.select_topn_ranges(got[:, 0], m, 16, t)
+    r_ref = orc.select_topn_ranges(got[:, 0].cpu().numpy(), mo, 16, t)
+    assert norm(r.cpu().numpy()) == norm(r_ref)
+
+
 def test_selector_vs_oracle_random_configs(nv, orc):
     """random (l', n_top, forced) configurations incl. wide rows (S_sel up to 2048)."""
     rng = np.random.default_rng(123)
