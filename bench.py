@@ -85,10 +85,11 @@ def decode_bench(nv, B, S_ctx, steps, device):
     q1 = Q[:, -1:].contiguous()
     t = S_ctx - 1
 
-    def step():
-        p_grp = nv.selection_scores(q1, Kc, meta, causal_skip=True)
-        r = nv.select_topn_ranges(p_grp[:, 0], meta, N_SEL, t)
-        return nv.selection_attention_hip(q1, K, V, r.unsqueeze(1))
+    O = torch.empty(B, 1, G, H, D, device=device, dtype=torch.bfloat16)
+    rg = torch.empty(B, G, N_SEL, 2, device=device, dtype=torch.int32)
+
+    def step():  # scores -> sequential top-n -> attention in one native call (nsa_sel_decode_step)
+        return nv.selection_decode_step(q1, Kc, K, V, meta, N_SEL, t, out=O, ranges_out=rg)
 
     ms = time_events(step, steps, warm=3)
     return B / (ms * 1e-3), ms

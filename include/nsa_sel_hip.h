@@ -156,6 +156,22 @@ NSA_API int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, 
                            int S_total /* batched: the S the forced-column rule is evaluated for */,
                            int32_t *ranges_out, int out_width, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * One decode step of the selected branch in ONE call (host launch overhead matters at batch 1):
+ *   Q [B,1,G,h,Dk] -> decode-shaped scores -> sequential top-n ranges at token t_token -> selection attention over
+ *   K/V[:, :, :S_kv].  Replaces the calls of the decode branch of NSAAttention.forward
+ *   (nsa/core/nsa_attention.py:651 compute_pcmp_all, :658 map_pcmp_to_pslc_batched, :670 head sum,
+ *   :672 select_topn_ranges, :704-830 selection executor).
+ *   ranges_out [B,G,n_top,2] int32, O [B,1,G,h,Dv]; workspace: nsa_sel_decode_step_workspace() bytes, 16-B aligned.
+ * ------------------------------------------------------------------------------------- */
+NSA_API size_t nsa_sel_decode_step_workspace(int B, int G, int h, int Dk, int Dv, int S_cmp, int S_sel, int n_top, int dtype);
+NSA_API int nsa_sel_decode_step(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr,
+                        const int32_t *csc_rows, const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h,
+                        int Dk, int Dv, int S_cmp, int S_sel, int S_kv, int l, int d, int l_sel, int n_top, int t_token,
+                        int64_t kc_stride_b, int64_t kc_stride_g, int64_t kc_stride_s, int64_t k_stride_b,
+                        int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b, int64_t v_stride_g,
+                        int64_t v_stride_s, int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream);
+
 /* indices [R,K] int32 ascending with -1 padding -> ranges [R,K,2]; clamp end to t+1. */
 NSA_API int nsa_indices_to_ranges_v2(const int32_t *indices, int64_t R, int S, int G, int t0, int K, int S_sel,
                              int l_sel, int32_t *ranges_out, void *stream);

@@ -11,6 +11,7 @@ from .selection_attention import (  # noqa: F401
     grouped_selection_attention_masked,
     hip_sel_available,
     selection_attention_hip,
+    selection_decode_step,
 )
 from .selection_scorer import (  # noqa: F401
     batched_ranges_width,

@@ -309,6 +309,39 @@ int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, int t0, 
                               ranges_out, out_width, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------------------ fused decode step
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+size_t nsa_sel_decode_step_workspace(int B, int G, int h, int Dk, int Dv, int S_cmp, int S_sel, int n_top, int dtype) {
+    const size_t a = align16(nsa_sel_scores_workspace(B, 1, G, h, Dk, S_cmp, S_sel, 0, 0, 0, dtype, 3));
+    const size_t p = align16(sizeof(float) * (size_t)B * G * (size_t)(S_sel > 0 ? S_sel : 1));
+    const size_t c = align16(nsa_sel_attn_fwd_workspace(B, 1, G, h, Dk, Dv, n_top, dtype));
+    return a + p + c;
+}
+
+int nsa_sel_decode_step(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr,
+                        const int32_t *csc_rows, const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h, int Dk,
+                        int Dv, int S_cmp, int S_sel, int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb,
+                        int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
+                        int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 16 == 0) &&
+                      workspace_bytes >= nsa_sel_decode_step_workspace(B, G, h, Dk, Dv, S_cmp, S_sel, n_top, dtype),
+                  "decode_step: workspace missing, misaligned or too small");
+    NSA_CHECK_ARG(n_top >= 1 && n_top <= 64, "decode_step: n_top must be in [1,64]");
+    unsigned char *w = (unsigned char *)workspace;
+    const size_t a = align16(nsa_sel_scores_workspace(B, 1, G, h, Dk, S_cmp, S_sel, 0, 0, 0, dtype, 3));
+    const size_t p = align16(sizeof(float) * (size_t)B * G * (size_t)(S_sel > 0 ? S_sel : 1));
+    float *p_grp = (float *)(w + a);
+    int rc = nsa_sel_scores(Q, K_cmp, p_grp, B, 1, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l, d, l_sel, 1,
+                            S_cmp >= 1 ? 3 : 1, dtype, scale, w, a, stream);
+    if (rc) return rc;
+    rc = nsa_select_topn_ranges(p_grp, (int64_t)B * G, 1, G, t_token, nullptr, S_sel, l_sel, n_top, 1, 2, NSA_SEL_SEQUENTIAL, 1,
+                                ranges_out, n_top, stream);
+    if (rc) return rc;
+    return nsa_sel_attn_fwd(Q, K, V, ranges_out, O, nullptr, B, 1, G, h, Dk, Dv, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, dtype,
+                            scale, 0, w + a + p, workspace_bytes - a - p, stream);
+}
+
 int nsa_indices_to_ranges_v2(const int32_t *indices, int64_t R, int S, int G, int t0, int K, int S_sel, int l_sel,
                              int32_t *ranges_out, void *stream) {
     NSA_CHECK_ARG((indices && ranges_out) || R == 0 || K == 0, "indices_to_ranges_v2: null pointer");

@@ -104,6 +104,39 @@ def selection_attention_hip(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, r
     return (O, lse) if return_lse else O
 
 
+def selection_decode_step(Q: torch.Tensor, K_cmp: torch.Tensor, K: torch.Tensor, V: torch.Tensor, meta, n_top: int, t_token: int,
+                          *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
+                          ranges_out: Optional[torch.Tensor] = None):
+    """One decode step of the selected branch in a single native call.
+
+    Q [B,1,G,h,Dk], K_cmp [B,G,S_cmp,Dk], K/V [B,G,S_kv,D] (views of a preallocated cache are fine), meta = BlockMeta
+    covering t_token.  Returns (O [B,1,G,h,Dv], ranges [B,G,n_top,2] int32) = what the decode branch of the
+    reference computes with compute_pcmp_all -> map_pcmp_to_pslc_batched -> sum(dim=3) -> select_topn_ranges ->
+    selection executor (nsa/core/nsa_attention.py:651-672, 704-830), sequential-selector semantics."""
+    dev = _need_gpu(Q, K_cmp, K, V)
+    B, S, G, h, Dk = Q.shape
+    if S != 1:
+        raise RuntimeError("selection_decode_step: decode requires S == 1")
+    S_kv, Dv = K.shape[2], V.shape[3]
+    S_cmp, S_sel = K_cmp.shape[2], meta.S_sel
+    Qc, Kc, Kk, Vv = Q.contiguous(), _prep_kv(K_cmp), _prep_kv(K), _prep_kv(V)
+    O = out if out is not None else torch.empty((B, 1, G, h, Dv), dtype=V.dtype, device=dev)
+    rg = ranges_out if ranges_out is not None else torch.empty((B, G, n_top, 2), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    dt = _DT[Q.dtype]
+    ws = workspace(dev, L.nsa_sel_decode_step_workspace(B, G, h, Dk, Dv, S_cmp, S_sel, n_top, dt) + 16, "decode")
+    wptr = (ws.data_ptr() + 15) & ~15
+    cptr, crows, cvals = meta.device_csc(dev)
+    rc = L.nsa_sel_decode_step(Qc.data_ptr(), Kc.data_ptr(), Kk.data_ptr(), Vv.data_ptr(), cptr.data_ptr(), crows.data_ptr(),
+                               cvals.data_ptr(), rg.data_ptr(), O.data_ptr(), B, G, h, Dk, Dv, S_cmp, S_sel, S_kv,
+                               int(meta.l), int(meta.d), int(meta.l_sel), int(n_top), int(t_token),
+                               Kc.stride(0), Kc.stride(1), Kc.stride(2), Kk.stride(0), Kk.stride(1), Kk.stride(2),
+                               Vv.stride(0), Vv.stride(1), Vv.stride(2), dt, float(scale) if scale else 0.0,
+                               wptr, ws.numel() - (wptr - ws.data_ptr()), _stream(dev))
+    _lib.check(rc, "nsa_sel_decode_step")
+    return O, rg
+
+
 # the reference's executor names, bound to the HIP implementation
 grouped_selection_attention_masked = selection_attention_hip
 selection_attention_cuda = selection_attention_hip

@@ -214,6 +214,32 @@ def test_decode_scorer_vs_oracle(nv, orc, S_ctx, B, h, D, geom, dtype):
     assert norm(r.cpu().numpy()) == norm(r_ref)
 
 
+@pytest.mark.parametrize("S_ctx,B", [(65536, 1), (16384, 5), (200, 3), (70, 2)])
+def test_fused_decode_step(nv, orc, S_ctx, B):
+    """nsa_sel_decode_step == the three separate calls, and == the oracle's decode chain (bf16, m7c shape)."""
+    rng = np.random.default_rng([S_ctx, B])
+    G, h, D, n = 2, 6, 64, 16
+    m = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mo = orc.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    dt = torch.bfloat16
+    Q = rng.standard_normal((B, 1, G, h, D), dtype=np.float32)
+    Kc = rng.standard_normal((B, G, m.S_cmp, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_ctx + 37, D), dtype=np.float32)  # preallocated cache longer than the context
+    V = rng.standard_normal((B, G, S_ctx + 37, D), dtype=np.float32)
+    t = S_ctx - 1
+    Kd, Vd = dev(K, dt), dev(V, dt)
+    O, rg = nv.selection_decode_step(dev(Q, dt), dev(Kc, dt), Kd[:, :, :S_ctx], Vd[:, :, :S_ctx], m, n, t)
+    p = nv.selection_scores(dev(Q, dt), dev(Kc, dt), m)
+    r2 = nv.select_topn_ranges(p[:, 0], m, n, t)
+    O2 = nv.selection_attention_hip(dev(Q, dt), Kd[:, :, :S_ctx], Vd[:, :, :S_ctx], r2.unsqueeze(1))
+    assert torch.equal(rg, r2) and torch.equal(O, O2)
+    rd = lambda a: torch.from_numpy(a).to(dt).float().numpy()  # noqa: E731
+    r_ref = orc.select_topn_ranges(p[:, 0].cpu().numpy(), mo, n, t)
+    assert norm(rg.cpu().numpy()) == norm(r_ref)
+    O_ref = orc.sel_attention_masked(rd(Q), rd(K[:, :, :S_ctx]), rd(V[:, :, :S_ctx]), rg.cpu().numpy()[:, None])
+    assert np.abs(O.float().cpu().numpy() - O_ref).max() <= 1e-2
+
+
 def test_selector_vs_oracle_random_configs(nv, orc):
     """random (l', n_top, forced) configurations incl. wide rows (S_sel up to 2048)."""
     rng = np.random.default_rng(123)

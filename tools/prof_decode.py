@@ -26,10 +26,16 @@ V = torch.randn(B, 2, S, 64, device="cuda", generator=g).bfloat16()
 t = S - 1
 
 
+O_buf = torch.empty(B, 1, 2, 6, 64, device="cuda", dtype=torch.bfloat16)
+R_buf = torch.empty(B, 2, 16, 2, device="cuda", dtype=torch.int32)
+
+
 def step():
-    p = nv.selection_scores(Q, Kc, meta, causal_skip=True)
-    r = nv.select_topn_ranges(p[:, 0], meta, 16, t)
-    return nv.selection_attention_hip(Q, K, V, r.unsqueeze(1))
+    if os.environ.get("NSA_DECODE_SEPARATE"):
+        p = nv.selection_scores(Q, Kc, meta, causal_skip=True)
+        r = nv.select_topn_ranges(p[:, 0], meta, 16, t)
+        return nv.selection_attention_hip(Q, K, V, r.unsqueeze(1))
+    return nv.selection_decode_step(Q, Kc, K, V, meta, 16, t, out=O_buf, ranges_out=R_buf)
 
 
 for _ in range(5):
