@@ -28,3 +28,5 @@ from .selection_scorer import (  # noqa: F401
 )
 
 __version__ = "0.1.0"
+from .kv_cache import NSA_KV  # noqa: E402,F401
+from .nsa_attention import GateMLP, NSAAttention  # noqa: E402,F401

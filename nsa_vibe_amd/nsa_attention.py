@@ -1,0 +1,243 @@
+"""NSAAttention with the selected branch on MI355X.
+
+Same operator surface as the reference module (nsa/core/nsa_attention.py:188-206 constructor, :509 forward(x, kv, *,
+prefill) -> (out, kv), :407-445 monitor getters) and the same state-dict keys (W_Q, W_K_sel, W_V_sel, W_K_win,
+W_V_win, W_K_cmp, W_V_cmp, out, gate.fc1, gate.fc2), so a checkpoint of the reference loads unchanged.
+
+What runs where:
+  * selected branch (the hot path): scores -> top-n ranges -> selection attention on the HIP kernels
+    (selection_scorer.py / selection_attention.py); no Python loop over t, no host sync, no O(S^2) mask.
+    Semantics = the reference's masked route (NSA_FORCE_SEL_MASK=1, the production setting).
+  * projections, RoPE, avg-pool phi, gate MLP, compressed and sliding branches: plain PyTorch-ROCm ops (out of
+    scope of the hot path).  The compressed / sliding branches use true causal softmax
+    attention; the reference's default SDPA routes for them degenerate to "first key only" for single-query calls
+    (is_causal=True with L_q=1) -- a quirk that is deliberately not reproduced.
+Selector semantics: `selector="sequential"` (reference default prefill, :1521-1723, and decode) or `"batched"`
+(NSA_PREFILL_BATCHED=1, :978-1448).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .kv_cache import NSA_KV
+from .selection_attention import selection_attention_hip, selection_decode_step
+from .selection_scorer import select_topn_ranges_batched, select_topn_ranges_rows, selection_scores
+
+
+def apply_rope(x: torch.Tensor, pos: torch.Tensor, base: float = 10000.0, scale: float = 1.0) -> torch.Tensor:
+    """Rotary embedding over adjacent pairs of the last dim, angles in fp32 (formula of nsa/core/rope.py:16-51).
+    x [..., S, D], pos [S]."""
+    D = x.shape[-1]
+    inv_freq = base ** (-2.0 * torch.arange(D // 2, device=x.device, dtype=torch.float32) / D)
+    ang = (pos.to(torch.float32) / (scale if scale > 0 else 1.0)).unsqueeze(-1) * inv_freq  # [S, D/2]
+    sin, cos = torch.sin(ang).to(x.dtype), torch.cos(ang).to(x.dtype)
+    x2 = x.reshape(*x.shape[:-1], D // 2, 2)
+    x0, x1 = x2[..., 0], x2[..., 1]
+    return torch.stack((x0 * cos - x1 * sin, x0 * sin + x1 * cos), dim=-1).reshape(x.shape)
+
+
+def avg_pool_phi(K_rope: torch.Tensor, V: torch.Tensor, l: int, d: int):
+    """phi = mean over windows of l tokens, stride d, on RoPE'd K and raw V (nsa/core/compress_pool.py:9-38)."""
+    B, G, S, Dk = K_rope.shape
+    if S < l:
+        return K_rope[:, :, :0], V[:, :, :0]
+    pool = lambda X: F.avg_pool1d(X.reshape(B * G, S, -1).transpose(1, 2), kernel_size=l, stride=d).transpose(1, 2)  # noqa: E731
+    Kc, Vc = pool(K_rope), pool(V)
+    return Kc.reshape(B, G, Kc.shape[1], Dk), Vc.reshape(B, G, Vc.shape[1], V.shape[-1])
+
+
+class GateMLP(nn.Module):
+    """Same parameters / init as the reference gate (nsa_attention.py:32-82): softmax over (cmp, sel, win)."""
+
+    def __init__(self, d_k: int, hidden: Optional[int] = None):
+        super().__init__()
+        hidden = hidden or max(1, d_k // 2)
+        self.fc1 = nn.Linear(d_k, hidden)
+        self.fc2 = nn.Linear(hidden, 3)
+        nn.init.xavier_uniform_(self.fc2.weight, gain=0.1)
+        nn.init.zeros_(self.fc2.bias)
+
+    def forward(self, q_pooled: torch.Tensor, tau: float = 1.0) -> torch.Tensor:
+        g = self.fc2(F.silu(self.fc1(q_pooled))) / max(tau, 1e-6)
+        p = F.softmax(g, dim=-1)
+        top2 = torch.topk(g.detach(), k=2, dim=-1).values
+        peaked = (top2[..., 0] - top2[..., 1]) > 50.0  # hard one-hot when extremely peaked (reference :70-81), sync free
+        one_hot = F.one_hot(torch.argmax(g, dim=-1), 3).to(p.dtype)
+        return torch.where(peaked.unsqueeze(-1), one_hot, p)
+
+
+def _masked_sdpa(Q, K, V, allowed):
+    """Q [B,Sq,G,h,D], K/V [B,G,Skv,D], allowed [Sq,Skv] bool -> [B,Sq,G,h,Dv]; rows without any key give zeros."""
+    B, Sq, G, h, D = Q.shape
+    if K.shape[2] == 0:
+        return Q.new_zeros((B, Sq, G, h, V.shape[-1]))
+    q = Q.permute(0, 2, 3, 1, 4).reshape(B, G * h, Sq, D)
+    k = K.unsqueeze(2).expand(-1, -1, h, -1, -1).reshape(B, G * h, K.shape[2], D)
+    v = V.unsqueeze(2).expand(-1, -1, h, -1, -1).reshape(B, G * h, V.shape[2], V.shape[-1])
+    any_key = allowed.any(dim=-1)
+    safe = allowed.clone()
+    safe[~any_key, 0] = True
+    mask = torch.zeros(safe.shape, dtype=Q.dtype, device=Q.device).masked_fill(~safe, float("-inf"))
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    o = o * any_key.view(1, 1, Sq, 1).to(o.dtype)
+    return o.reshape(B, G, h, Sq, -1).permute(0, 3, 1, 2, 4)
+
+
+class NSAAttention(nn.Module):
+    def __init__(self, dim: int, n_heads: int, n_kv_groups: int, d_k: int, d_v: int, l: int = 32, d: int = 16, l_sel: int = 64,
+                 n_sel: int = 16, w: int = 512, phi: str = "avg", gate_hidden: Optional[int] = None, gate_temp: float = 1.0,
+                 rope_impl: str = "llama", use_flash: bool = True, use_triton_sel: bool = False, *,
+                 selector: Optional[str] = None, query_chunk: int = 2048) -> None:
+        super().__init__()
+        assert n_heads % n_kv_groups == 0, "heads must be divisible by kv groups"
+        if l % d != 0 or l_sel % d != 0:
+            raise ValueError("M0 requires d|l and d|l_sel; set valid block sizes/stride.")
+        if (phi or "avg").lower() != "avg":
+            raise ValueError("only phi='avg' is provided (the reference's learnable phi is disabled by a bug, SURVEY 4)")
+        self.dim, self.n_heads, self.n_kv_groups, self.h_per_group = dim, n_heads, n_kv_groups, n_heads // n_kv_groups
+        self.d_k, self.d_v, self.l, self.d, self.l_sel, self.n_sel, self.w = d_k, d_v, l, d, l_sel, n_sel, w
+        self.gate_temp = gate_temp
+        self.rope_scale = float(os.getenv("NSA_ROPE_SCALE", "1.0") or 1.0)
+        if selector is None:
+            selector = "batched" if os.getenv("NSA_PREFILL_BATCHED", "0").lower() in ("1", "true", "yes") else "sequential"
+        assert selector in ("sequential", "batched")
+        self.selector = selector
+        self.query_chunk = query_chunk
+        self.W_Q = nn.Linear(dim, n_heads * d_k, bias=False)
+        self.W_K_sel = nn.Linear(dim, n_kv_groups * d_k, bias=False)
+        self.W_V_sel = nn.Linear(dim, n_kv_groups * d_v, bias=False)
+        self.W_K_win = nn.Linear(dim, n_kv_groups * d_k, bias=False)
+        self.W_V_win = nn.Linear(dim, n_kv_groups * d_v, bias=False)
+        self.W_K_cmp = nn.Linear(dim, n_kv_groups * d_k, bias=False)
+        self.W_V_cmp = nn.Linear(dim, n_kv_groups * d_v, bias=False)
+        self.out = nn.Linear(n_heads * d_v, dim, bias=False)
+        self.gate = GateMLP(d_k, gate_hidden)
+        self._last_gates: Optional[torch.Tensor] = None
+        self._last_ranges: Optional[torch.Tensor] = None
+        self._fallback_counters = {k: 0 for k in ("selection_triton_fails", "selection_cuda_fails", "selection_hip_fails",
+                                                  "selection_pack_fails", "selection_mask_fails", "compressed_fa2_fails",
+                                                  "sliding_fa2_fails", "total_fallbacks")}
+
+    # ---- cache -------------------------------------------------------------------------------
+    def new_kv(self, B: int, S_max: int, device, dtype) -> NSA_KV:
+        return NSA_KV(B, self.n_kv_groups, self.d_k, self.d_v, S_max, self.l, self.d, self.l_sel, self.n_sel, self.w, device, dtype)
+
+    # ---- monitors (reference :407-445); computed on demand so the forward pass never syncs -----
+    def get_gate_stats(self) -> Optional[dict]:
+        g = self._last_gates
+        if g is None:
+            return None
+        g = g.detach().float().reshape(-1, 3)
+        ent = -(g * (g + 1e-8).log()).sum(-1)
+        return {"entropy_mean": float(ent.mean()), "entropy_min": float(ent.min()), "max_gate_mean": float(g.max(-1).values.mean()),
+                "max_gate_max": float(g.max()), "branch_shares": [float(x) for x in g.mean(0)]}
+
+    def get_fallback_counters(self) -> dict:
+        return self._fallback_counters.copy()
+
+    def reset_fallback_counters(self) -> dict:
+        prev = self._fallback_counters.copy()
+        for k in self._fallback_counters:
+            self._fallback_counters[k] = 0
+        return prev
+
+    def get_selection_stats(self) -> Optional[dict]:
+        r = self._last_ranges
+        if r is None:
+            return None
+        L = (r[..., 1] - r[..., 0]).clamp_min(0).sum(-1).to(torch.int64)
+        k_max = int(L.max()) if L.numel() else 0
+        return {"k_mean": float(L.float().mean()) if L.numel() else 0.0, "k_max": k_max, "rows": int(L.numel()),
+                "pct_at_max": float((L == k_max).float().mean()) if k_max > 0 else 0.0, "l_sel": self.l_sel, "n_sel": self.n_sel}
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _project(self, x: torch.Tensor, pos: torch.Tensor):
+        B, S, _ = x.shape
+        G, h = self.n_kv_groups, self.h_per_group
+        # the reference rotates Q over the flattened [n_heads*d_k] axis (nsa_attention.py:552-560,1002-1009) and K per group
+        Q = apply_rope(self.W_Q(x), pos, scale=self.rope_scale).view(B, S, G, h, self.d_k)
+        kv = lambda W: W(x).view(B, S, G, -1).permute(0, 2, 1, 3)  # noqa: E731  -> [B,G,S,D]
+        K_sel = apply_rope(kv(self.W_K_sel), pos, scale=self.rope_scale)
+        K_win = apply_rope(kv(self.W_K_win), pos, scale=self.rope_scale)
+        return Q, K_sel, kv(self.W_V_sel), K_win, kv(self.W_V_win), kv(self.W_K_cmp), kv(self.W_V_cmp)
+
+    def _combine(self, Q, O_cmp, O_sel, O_win):
+        B, S = Q.shape[:2]
+        gates = self.gate(Q.mean(dim=3), tau=self.gate_temp)  # [B,S,G,3]
+        self._last_gates = gates
+        O = gates[..., 0:1].unsqueeze(3) * O_cmp + gates[..., 1:2].unsqueeze(3) * O_sel + gates[..., 2:3].unsqueeze(3) * O_win
+        return self.out(O.reshape(B, S, self.n_heads * self.d_v))
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, kv: NSA_KV, *, prefill: bool):
+        assert x.dim() == 3, "x must be [B,S,dim]"
+        if prefill:
+            assert x.shape[1] > 0, f"Prefill mode requires S > 0, got S={x.shape[1]}"
+            return self._prefill(x, kv)
+        assert x.shape[1] == 1, f"Decode mode requires S=1 (single token), got S={x.shape[1]}."
+        return self._decode(x, kv)
+
+    def _prefill(self, x: torch.Tensor, kv: NSA_KV):
+        B, S, _ = x.shape
+        assert kv.t == 0, "prefill expects an empty cache"
+        pos = torch.arange(S, device=x.device)
+        Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = self._project(x, pos)
+        kv.write_tokens(K_sel, V_sel, K_win, V_win, K_raw, V_raw)
+        K_cmp, V_cmp = avg_pool_phi(apply_rope(K_raw, pos), V_raw, self.l, self.d)
+        kv.write_compressed(K_cmp, V_cmp, at=0)
+        meta = kv.ensure_meta(S)
+        scale = 1.0 / math.sqrt(self.d_k)
+        Qc = Q.contiguous()
+        # ---- selected branch (HIP): scores -> ranges -> attention
+        p_grp = selection_scores(Qc, kv.K_cmp, meta, scale, causal_skip=True)
+        if self.selector == "batched":
+            ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
+        else:
+            ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+        self._last_ranges = ranges
+        O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
+        # ---- compressed + sliding branches (torch, query-chunked masks)
+        O_cmp, O_win = torch.empty_like(O_sel), torch.empty_like(O_sel)
+        n_cmp_all = kv.n_cmp
+        for s0 in range(0, S, self.query_chunk):
+            s1 = min(S, s0 + self.query_chunk)
+            t = torch.arange(s0, s1, device=x.device).view(-1, 1)
+            num_cmp = torch.where(t + 1 < self.l, 0, (t + 1 - self.l) // self.d + 1).clamp(max=n_cmp_all)
+            O_cmp[:, s0:s1] = _masked_sdpa(Q[:, s0:s1], kv.K_cmp, kv.V_cmp, torch.arange(n_cmp_all, device=x.device).view(1, -1) < num_cmp)
+            k0 = max(0, s0 - self.w + 1)
+            col = torch.arange(k0, s1, device=x.device).view(1, -1)
+            O_win[:, s0:s1] = _masked_sdpa(Q[:, s0:s1], kv._K_win[:, :, k0:s1], kv._V_win[:, :, k0:s1], (col <= t) & (col > t - self.w))
+        return self._combine(Q, O_cmp, O_sel, O_win), kv
+
+    def _decode(self, x: torch.Tensor, kv: NSA_KV):
+        t = kv.t  # position of the new token
+        pos = torch.tensor([t], device=x.device)
+        Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = self._project(x, pos)
+        kv.write_tokens(K_sel, V_sel, K_win, V_win, K_raw, V_raw)
+        S_raw = kv.t
+        if S_raw >= self.l and (S_raw - self.l) % self.d == 0:  # emit one compressed token (reference :588-604)
+            p_last = torch.arange(S_raw - self.l, S_raw, device=x.device)
+            K_new = apply_rope(kv._K_raw[:, :, S_raw - self.l: S_raw], p_last).mean(dim=2, keepdim=True)
+            V_new = kv._V_raw[:, :, S_raw - self.l: S_raw].mean(dim=2, keepdim=True)
+            kv.write_compressed(K_new.to(kv._K_cmp.dtype), V_new.to(kv._V_cmp.dtype))
+        # block metadata refresh policy of the reference (:606-632): rebuild only when t leaves the covered blocks
+        if kv.meta.S_sel == 0:
+            kv.ensure_meta(max(t + 1, self.l_sel))
+        elif t + 1 > kv.meta.S_sel * self.l_sel:
+            kv.ensure_meta(t + 1)
+        num_cmp = 0 if S_raw < self.l else (S_raw - self.l) // self.d + 1
+        kv.append_reads(num_cmp, S_raw)
+        scale = 1.0 / math.sqrt(self.d_k)
+        Qc = Q.contiguous()
+        O_sel, ranges = selection_decode_step(Qc, kv.K_cmp, kv.K_sel, kv.V_sel, kv.meta, self.n_sel, t, scale=scale)
+        self._last_ranges = ranges
+        ones = lambda n: torch.ones((1, n), dtype=torch.bool, device=x.device)  # noqa: E731
+        O_win = _masked_sdpa(Q, kv.K_win, kv.V_win, ones(kv.K_win.shape[2]))
+        O_cmp = _masked_sdpa(Q, kv.K_cmp, kv.V_cmp, ones(kv.n_cmp)) if kv.n_cmp > 0 else torch.zeros_like(O_sel)
+        return self._combine(Q, O_cmp, O_sel, O_win), kv

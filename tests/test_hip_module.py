@@ -1,0 +1,102 @@
+"""GPU: the NSAAttention drop-in (nsa_vibe_amd/nsa_attention.py) against outputs of the REFERENCE module
+(oracle/make_module_goldens.py: production route NSA_FORCE_SEL_MASK=1, gate forced onto the selected branch, the
+setup of the reference's test_equiv_full_coverage.py:72), prefill in both selector modes + 24 decode steps."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(g, selector, dtype=torch.float32):
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    dim, H, G, dk, dv, l, d, ls, n, w = (int(x) for x in g["cfg"])
+    m = NSAAttention(dim, H, G, dk, dv, l=l, d=d, l_sel=ls, n_sel=n, w=w, selector=selector)
+    state = {k[6:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("state_")}
+    m.load_state_dict(state)  # reference checkpoint keys load unchanged
+    with torch.no_grad():
+        m.gate.fc2.bias.copy_(torch.tensor([-1000.0, 1000.0, -1000.0]))
+    return m.cuda().to(dtype).eval()
+
+
+@pytest.mark.parametrize("selector", ["sequential", "batched"])
+def test_module_matches_reference_fp32(selector):
+    g = load_golden("g12_module")
+    m = _module(g, selector)
+    x_pre = torch.from_numpy(g["x_pre"]).cuda()
+    x_dec = torch.from_numpy(g["x_dec"]).cuda()
+    tag = "seq" if selector == "sequential" else "bat"
+    with torch.no_grad():
+        out, kv = m(x_pre, m.new_kv(x_pre.shape[0], x_pre.shape[1], "cuda", torch.float32), prefill=True)
+        assert np.abs(out.cpu().numpy() - g[f"out_pre_{tag}"]).max() <= 1e-3
+        # decode from an empty cache, 100 steps (the reference's prefill-via-decode flow; see make_module_goldens.py for
+        # why decode-after-prefill of the reference is not usable as an oracle)
+        kv = m.new_kv(x_dec.shape[1], x_dec.shape[0], "cuda", torch.float32)
+        for i in range(x_dec.shape[0]):
+            o, kv = m(x_dec[i], kv, prefill=False)
+            assert np.abs(o.cpu().numpy() - g[f"out_dec_{tag}"][i]).max() <= 1e-3, i
+    assert kv.t == x_dec.shape[0]
+    st = m.get_selection_stats()
+    assert st["rows"] == x_dec.shape[1] * 2 and st["k_max"] <= 4 * 16
+    gs = m.get_gate_stats()
+    assert abs(gs["branch_shares"][1] - 1.0) < 1e-6
+    assert m.get_fallback_counters()["total_fallbacks"] == 0 and len(kv.reads_pred) == x_dec.shape[0]
+
+
+def test_decode_after_prefill_is_consistent():
+    """prefill(x[:S]) then decode(x[S:]) == decode(x) from an empty cache: same cache contents (K/V, compressed tokens on
+    the absolute emission schedule) and same decode outputs -- the consistency the reference's cache bookkeeping lacks."""
+    g = load_golden("g12_module")
+    m = _module(g, "sequential")
+    x = torch.from_numpy(g["x_dec"]).cuda()[:, :, 0].transpose(0, 1).contiguous()  # [B, 100, dim]
+    S = 61
+    with torch.no_grad():
+        kv_a = m.new_kv(x.shape[0], x.shape[1], "cuda", torch.float32)
+        _, kv_a = m(x[:, :S], kv_a, prefill=True)
+        kv_b = m.new_kv(x.shape[0], x.shape[1], "cuda", torch.float32)
+        for t in range(S):
+            _, kv_b = m(x[:, t: t + 1], kv_b, prefill=False)
+        assert kv_a.t == kv_b.t == S and kv_a.n_cmp == kv_b.n_cmp == (S - 8) // 4 + 1
+        for name in ("K_sel", "V_sel", "K_cmp", "V_cmp", "K_cmp_raw_seq"):
+            assert (getattr(kv_a, name) - getattr(kv_b, name)).abs().max().item() <= 1e-5, name
+        for t in range(S, x.shape[1]):
+            oa, kv_a = m(x[:, t: t + 1], kv_a, prefill=False)
+            ob, kv_b = m(x[:, t: t + 1], kv_b, prefill=False)
+            assert (oa - ob).abs().max().item() <= 1e-4, t
+
+
+def test_module_bf16_close_to_reference():
+    g = load_golden("g12_module")
+    m = _module(g, "sequential", torch.bfloat16)
+    x_pre = torch.from_numpy(g["x_pre"]).cuda().bfloat16()
+    kv = m.new_kv(x_pre.shape[0], 128, "cuda", torch.bfloat16)
+    with torch.no_grad():
+        out, kv = m(x_pre, kv, prefill=True)
+    ref = g["out_pre_seq"]
+    err = np.abs(out.float().cpu().numpy() - ref)
+    # bf16 end to end (weights, activations, RoPE tables): selection can flip on near ties, so bound the typical row
+    assert np.median(err.max(axis=-1)) <= 5e-2
+
+
+def test_module_full_gates_runs_and_is_causal():
+    """all three branches + learned gate: finite outputs, and prefill row t does not depend on tokens > t."""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    torch.manual_seed(0)
+    m = NSAAttention(256, 8, 2, 32, 32, l=32, d=16, l_sel=64, n_sel=8, w=128).cuda().bfloat16().eval()
+    x = torch.randn(2, 700, 256, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        o1, _ = m(x, m.new_kv(2, 700, "cuda", torch.bfloat16), prefill=True)
+        x2 = x.clone()
+        x2[:, 500:] = torch.randn_like(x2[:, 500:])
+        o2, _ = m(x2, m.new_kv(2, 700, "cuda", torch.bfloat16), prefill=True)
+    assert torch.isfinite(o1).all()
+    # NOTE: the selection scores normalise over ALL compressed tokens, also future ones (reference behaviour,
+    # selection_scorer.py:42-61).  The per-head normalisers differ, so a change of future tokens can re-rank the group
+    # scores of a few rows: prefill selection is only approximately causal in the reference, and so here.  The compressed
+    # and sliding branches and the attention itself are strictly causal: most rows must be unchanged.
+    same = ((o1[:, :480] - o2[:, :480]).abs().amax(dim=-1) <= 3e-2).float().mean().item()
+    assert same >= 0.8
