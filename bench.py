@@ -127,6 +127,16 @@ def cpu_baseline(S, B, seed=3, min_seconds=10.0):
             "cpu_model": _cpu_model()}
 
 
+def pmc_traffic(S, B):
+    """HBM bytes per launch of the attention kernel for this workload, measured with rocprofv3 PMC counters in separate
+    passes and committed under profiles/ (bench.py cannot run the profiler on itself); None if not measured."""
+    path = os.path.join(ROOT, "profiles", "r01", f"traffic_S{S}_B{B}.json")
+    try:
+        return float(json.load(open(path))["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -201,7 +211,9 @@ def main():
         achieved = alg_bytes / (t_att * 1e-3) / 1e9
         flops = 4.0 * H * Lsum * D
         out["roofline"] = {"kernel": "sel_attn_fwd_mfma_kernel<bf16,64>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(S, B),
+                           "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01/traffic_*.json); the gather is "
+                                           "L2 / Infinity-Cache resident, so achieved (algorithmic) exceeds what reaches HBM",
                            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
                            "mfma_tflops": flops / (t_att * 1e-3) / 1e12, "mfma_frac": flops / (t_att * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att}
