@@ -88,14 +88,18 @@ NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const 
                      int64_t v_stride_g, int64_t v_stride_s, int dtype, float scale, int variant,
                      void *workspace, size_t workspace_bytes, void *stream);
 
-/* Backward.  dO like O; dQ like Q (dtype); dK/dV are fp32 [B,G,S_kv,D] contiguous accumulators that
- * the callee zero-fills first (one fp32 atomic add per selected (row,token) element).
- * O and lse come from the forward. */
+/* Backward.  dO like O; dQ like Q (dtype); dK/dV are fp32 [B,G,S_kv,D] contiguous, fully written by the callee.
+ * O and lse come from the forward.
+ *   variant 0 auto, 1 generic (any dtype/shape: one wave per query row, dK/dV by fp32 atomics),
+ *   2 MFMA (bf16/f16, Dk = Dv = 64, h <= 16): dQ query-major + dK/dV key-block-major, no atomics, reproducible.
+ *   workspace: nsa_sel_attn_bwd_workspace() bytes (B*S*G*h floats for the MFMA route, else 0). */
+NSA_API size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int variant);
 NSA_API int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t *ranges, const void *O,
                      const float *lse, const void *dO, void *dQ, float *dK, float *dV, int B, int S,
                      int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t k_stride_b,
                      int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b, int64_t v_stride_g,
-                     int64_t v_stride_s, int dtype, float scale, void *stream);
+                     int64_t v_stride_s, int dtype, float scale, int variant, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Eq.9 map in gather (CSC) form.  For selection block j the entries csc_ptr[j]..csc_ptr[j+1]

@@ -129,19 +129,33 @@ int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t 
     return launch_sel_attn_fwd_generic(P, dtype, st);
 }
 
+size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int variant) {
+    if (variant == 1 || !sel_attn_bwd_mfma_supported(dtype, h, Dk, Dv)) return 0;
+    return sel_attn_bwd_mfma_workspace((int64_t)B * S * G, h);
+}
+
 int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t *ranges, const void *O,
                      const float *lse, const void *dO, void *dQ, float *dK, float *dV, int B, int S, int G, int h,
                      int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
-                     int64_t vsg, int64_t vss, int dtype, float scale, void *stream) {
+                     int64_t vsg, int64_t vss, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes,
+                     void *stream) {
     NSA_CHECK_ARG(dtype_ok(dtype), "sel_attn_bwd: unknown dtype %d", dtype);
     NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0 && n_ranges >= 0,
                   "sel_attn_bwd: negative size");
     NSA_CHECK_ARG(n_ranges <= 64, "sel_attn_bwd: at most 64 ranges per row");
     NSA_CHECK_ARG(Dk <= 256 && Dv <= 256, "sel_attn_bwd: Dk/Dv up to 256 supported");
+    NSA_CHECK_ARG(variant >= 0 && variant <= 2, "sel_attn_bwd: unknown variant %d", variant);
     hipStream_t st = (hipStream_t)stream;
     const int64_t R = (int64_t)B * S * G;
     const size_t esz = dtype == NSA_DT_F32 ? 4 : 2;
-    if ((int64_t)B * G * S_kv > 0) {
+    const bool empty = R == 0 || S_kv == 0 || n_ranges == 0;
+    const bool fast_ok = !empty && sel_attn_bwd_mfma_supported(dtype, h, Dk, Dv) && kss % 8 == 0 && vss % 8 == 0 && ksb % 8 == 0 &&
+                         vsb % 8 == 0 && ksg % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) &&
+                         ((uintptr_t)V % 16 == 0) && ((uintptr_t)dO % 16 == 0) && ((uintptr_t)O % 16 == 0) && (int64_t)B * G <= 65535 &&
+                         workspace && workspace_bytes >= sel_attn_bwd_mfma_workspace(R, h) && ((uintptr_t)workspace % 4 == 0);
+    if (variant == 2) NSA_CHECK_ARG(fast_ok, "sel_attn_bwd: MFMA variant requested but shape/dtype/alignment/workspace unsupported");
+    const bool fast = fast_ok && variant != 1;
+    if (!fast && (int64_t)B * G * S_kv > 0) {  // the generic kernel accumulates with atomics; the MFMA route writes every element
         NSA_HIP_TRY(hipMemsetAsync(dK, 0, sizeof(float) * (size_t)B * G * S_kv * Dk, st));
         NSA_HIP_TRY(hipMemsetAsync(dV, 0, sizeof(float) * (size_t)B * G * S_kv * Dv, st));
     }
@@ -156,6 +170,7 @@ int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t 
     P.R = R; P.S = S; P.G = G; P.h = h; P.Dk = Dk; P.Dv = Dv; P.S_kv = S_kv; P.n = n_ranges;
     P.ksb = ksb; P.ksg = ksg; P.kss = kss; P.vsb = vsb; P.vsg = vsg; P.vss = vss;
     P.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    if (fast) return launch_sel_attn_bwd_mfma(P, dtype, (float *)workspace, st);
     return launch_sel_attn_bwd_generic(P, dtype, st);
 }
 

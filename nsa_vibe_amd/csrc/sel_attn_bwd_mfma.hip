@@ -1,0 +1,478 @@
+// MFMA backward of the selection attention for gfx950 (bf16 / f16, Dk = Dv = 64, h <= 16).
+//
+// Reference: autograd of the masked SDPA (nsa/core/attention_kernels.py:705-772); the structure of the reference's
+// analytic backward (nsa/kernels/triton_sel_kernel/__init__.py:163-231: recompute P, dS = P*(dP - delta), dQ/dK/dV)
+// without its first-key quirk (:217-219).  P is recomputed from the forward's log-sum-exp.
+//
+// Three kernels, no atomics, bitwise reproducible:
+//   1. delta[row,h] = sum_dv dO*O.
+//   2. dQ, query-major (one wave per query row, the forward's mapping): per 32-key tile
+//        S^T = K.Q^T, dP^T = V.dO^T, dS^T = exp2(S^T c - lse) * (dP^T - delta) * scale, dQ^T += K^T.dS^T
+//      (K is staged twice in LDS: a row image for the S^T A-operand and a transposable image for the dQ^T A-operand.)
+//   3. dK, dV, KEY-BLOCK-major: one workgroup owns 64 keys of one (b,g) and keeps their dK/dV (64x64 fp32 each) in MFMA
+//      accumulators while it sweeps every query row that selected the block.  The rows are found by scanning the range
+//      lists (lane = row) and compacted in ascending t, so the summation order is fixed.  Rows are processed two at a
+//      time (2 x 6 heads = 12 of the 16 MFMA columns):  S = Q.K^T, dP = dO.V^T (16x16x32), then dV += P^T.dO and
+//      dK += dS^T.Q as 16x16x16 MFMAs whose A operand is taken straight from the S/dP accumulators (their row index,
+//      the (query,head) slot, is the contraction index) and whose B operand is read transposed from LDS.
+#include "nsa_common.hpp"
+#include "sel_attn_params.hpp"
+
+namespace nsa {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <typename T>
+struct BwdT;
+template <>
+struct BwdT<__bf16> {
+    using x8 = bf16x8;
+    using x4 = bf16x4;
+    __device__ static f32x4 mma32(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ static f32x4 mma16(x4 a, x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
+};
+template <>
+struct BwdT<_Float16> {
+    using x8 = f16x8;
+    using x4 = f16x4;
+    __device__ static f32x4 mma32(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    __device__ static f32x4 mma16(x4 a, x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename X4>
+__device__ __forceinline__ X4 tr_read(const unsigned char *p) {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+    return __builtin_bit_cast(X4, r);
+}
+
+constexpr int BD = 64;           // head dim handled here
+constexpr int BROWB = BD * 2;    // 128-B rows
+__device__ __forceinline__ int bswz_row(int r) { return r & 7; }          // 16-B piece XOR for b128 row reads
+__device__ __forceinline__ int bswz_tr(int r) { return (r >> 1) & 3; }    // 32-B chunk XOR for transposed reads
+__device__ __forceinline__ uint32_t off_row_img(int r, int piece) { return r * BROWB + ((piece ^ bswz_row(r)) << 4); }
+__device__ __forceinline__ uint32_t off_tr_img(int r, int piece) {
+    return r * BROWB + ((((piece >> 1) ^ bswz_tr(r)) << 5) | ((piece & 1) << 4));
+}
+
+// ------------------------------------------------------------------------------------------ 1. delta
+template <typename T>
+__global__ __launch_bounds__(256) void bwd_delta_kernel(const T *__restrict__ O, const T *__restrict__ dO, float *__restrict__ delta,
+                                                         int64_t n_rows, int Dv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const T *o = O + i * Dv, *g = dO + i * Dv;
+    float acc = 0.f;
+    for (int e = 0; e < Dv; e += 8) {
+        const u32x4 a = *(const u32x4 *)(o + e), b = *(const u32x4 *)(g + e);
+        const T *pa = (const T *)&a, *pb = (const T *)&b;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = fmaf(Elt<T>::to_f(pa[k]), Elt<T>::to_f(pb[k]), acc);
+    }
+    delta[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ 2. dQ (query-major)
+template <typename T>
+__global__ __launch_bounds__(256) void bwd_dq_kernel(SelAttnBwdParams P, const float *__restrict__ delta, int map_mode) {
+    using M = BwdT<T>;
+    using x8 = typename M::x8;
+    using x4 = typename M::x4;
+    constexpr int TILE = 32 * BROWB;  // 4 KiB
+    constexpr int SEGB = ((SEG_INTS * 4 + 15) / 16) * 16;
+    constexpr int WAVE_LDS = 3 * TILE + SEGB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (map_mode != 0) {  // same (b,g)-major / XCD-aware order as the forward kernel
+        const int W = (P.S + 3) >> 2;
+        int bg, tc;
+        if (map_mode == 2) {
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            bg = (idx / W) * 8 + xcd;
+            tc = idx % W;
+        } else {
+            bg = blockIdx.x / W;
+            tc = blockIdx.x % W;
+        }
+        const int t = 4 * tc + wave;
+        if (t >= P.S) return;
+        row = ((int64_t)(bg / P.G) * P.S + t) * P.G + (bg % P.G);
+    }
+    if (row >= P.R) return;
+    unsigned char *k_row = smem + (size_t)wave * WAVE_LDS;  // K, row image
+    unsigned char *k_tr = k_row + TILE;                     // K, transposable image
+    unsigned char *v_row = k_tr + TILE;                     // V, row image
+    int *seg = (int *)(v_row + TILE);
+
+    const int h = P.h;
+    const int g = (int)(row % P.G);
+    const int b = (int)(row / ((int64_t)P.G * P.S));
+    const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
+    const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
+    const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;
+    int nseg;
+    const int L = normalise_ranges(P.ranges + row * (int64_t)P.n * 2, P.n, P.S_kv, seg, &nseg);
+    const int rho = lane & 15, q = lane >> 4;
+
+    // B operands held for the whole row: Q^T and dO^T fragments (head = column), per-head lse (log2 domain) and delta
+    x8 qf[2], dof[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+        if (rho < h) {
+            a = *(const u32x4 *)((const T *)P.Q + (row * h + rho) * (int64_t)BD + 32 * s + 8 * q);
+            c = *(const u32x4 *)((const T *)P.dO + (row * h + rho) * (int64_t)BD + 32 * s + 8 * q);
+        }
+        qf[s] = __builtin_bit_cast(x8, a);
+        dof[s] = __builtin_bit_cast(x8, c);
+    }
+    const float lse2 = (rho < h && L > 0) ? P.lse[row * h + rho] * LOG2E : 0.f;
+    const float dlt = (rho < h) ? delta[row * h + rho] : 0.f;
+    const float c2 = P.scale * LOG2E;
+
+    const int ld_row = lane >> 3, ld_piece = lane & 7;  // 8 rows x 8 pieces per wave-wide 16-B load
+    uint32_t kd_row[4], kd_tr[4], vd_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + ld_row;
+        kd_row[i] = (uint32_t)(ld_row * krowb + ((ld_piece ^ bswz_row(r)) << 4));
+        kd_tr[i] = (uint32_t)(ld_row * krowb + (((((ld_piece >> 1) ^ bswz_tr(r)) << 1) | (ld_piece & 1)) << 4));
+        vd_row[i] = (uint32_t)(ld_row * vrowb + ((ld_piece ^ bswz_row(r)) << 4));
+    }
+    uint32_t rd_row[2], rd_tr[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rd_row[s] = off_row_img(rho, 4 * s + q);
+    {
+        const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) rd_tr[m] = r * BROWB + ((m ^ bswz_tr(r)) << 5) + 8 * pp;
+    }
+    auto make_rsrc = [&](const unsigned char *base, int64_t bytes) {
+        const uint64_t a = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + BROWB);
+    const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + BROWB);
+    const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    const int kstep = uniform(8 * (int)krowb), vstep = uniform(8 * (int)vrowb);
+
+    int it_seg = -1, it_start = 0, it_len = 0, it_pos = 0;
+    auto next_tile = [&](int &tok0, int &nvalid) -> bool {
+        while (true) {
+            if (it_pos < it_len) {
+                tok0 = it_start + it_pos;
+                nvalid = min(32, it_len - it_pos);
+                it_pos += 32;
+                return true;
+            }
+            if (++it_seg >= nseg) return false;
+            it_start = uniform(seg[2 * it_seg]);
+            it_len = uniform(seg[2 * it_seg + 3]) - uniform(seg[2 * it_seg + 1]);
+            it_pos = 0;
+        }
+    };
+    auto issue_dma = [&](int tok0, int nvalid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // tail tiles: rows past the segment re-read its last row (their dS is masked to zero below)
+            const int rowshift = (nvalid == 32) ? 0 : (min(8 * i + ld_row, nvalid - 1) - ld_row);
+            const int kso = (nvalid == 32) ? ks + i * kstep : ks, vso = (nvalid == 32) ? vs + i * vstep : vs;
+            const uint32_t kadd = (nvalid == 32) ? 0u : (uint32_t)(rowshift * krowb32), vadd = (nvalid == 32) ? 0u : (uint32_t)(rowshift * vrowb32);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(k_row + i * 1024), 16, kd_row[i] + kadd, kso, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(k_tr + i * 1024), 16, kd_tr[i] + kadd, kso, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(v_row + i * 1024), 16, vd_row[i] + vadd, vso, 0, 0);
+        }
+#else
+        (void)tok0;
+        (void)nvalid;
+#endif
+    };
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dq[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tok0 = 0, nvalid = 0;
+    bool have = next_tile(tok0, nvalid);
+    if (have) issue_dma(tok0, nvalid);
+    while (have) {
+        const int cur_nvalid = nvalid;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        x8 kfr[2][2], vfr[2][2];
+        x4 ktr[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kfr[u][s] = *(const x8 *)(k_row + rd_row[s] + u * 16 * BROWB);
+                vfr[u][s] = *(const x8 *)(v_row + rd_row[s] + u * 16 * BROWB);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ktr[u][m] = tr_read<x4>(k_tr + rd_tr[m] + u * 16 * BROWB);
+        have = next_tile(tok0, nvalid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (have) issue_dma(tok0, nvalid);
+
+        f32x4 sacc[2], pacc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            sacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sacc[u] = M::mma32(kfr[u][s], qf[s], sacc[u]);
+                pacc[u] = M::mma32(vfr[u][s], dof[s], pacc[u]);
+            }
+        }
+        x8 dsf;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][j], c2, -lse2));
+                if (16 * u + 4 * q + j >= cur_nvalid) p = 0.f;
+                dsf[4 * u + j] = Elt<T>::from_f(p * (pacc[u][j] - dlt) * P.scale);
+            }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            x8 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = ktr[0][m][j];
+                a[4 + j] = ktr[1][m][j];
+            }
+            dq[m] = M::mma32(a, dsf, dq[m]);
+        }
+    }
+    if (rho < h) {
+        T *dQr = (T *)P.dQ + (row * (int64_t)h + rho) * BD;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = Elt<T>::from_f(dq[m][j]);
+            *(x4 *)(dQr + 16 * m + 4 * q) = ov;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 3. dK / dV (key-block-major)
+constexpr int KB_NCT = 4;  // column tiles (of 16 (query,head) slots) staged per round
+
+template <typename T>
+__global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta) {
+    using M = BwdT<T>;
+    using x8 = typename M::x8;
+    using x4 = typename M::x4;
+    constexpr int SLOTS = 16 * KB_NCT;        // (query,head) slots per round
+    constexpr int IMG = SLOTS * BROWB;        // 8 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * BROWB + 4 * IMG];
+    __shared__ __attribute__((aligned(16))) float s_lse2[SLOTS], s_delta[SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_mask[SLOTS];
+    __shared__ int s_t[256];
+    __shared__ unsigned long long s_m[256];
+    __shared__ int s_cnt[5];
+    unsigned char *k_img = lds, *v_img = lds + 64 * BROWB;
+    unsigned char *q_row = lds + 2 * 64 * BROWB, *q_tr = q_row + IMG, *do_row = q_tr + IMG, *do_tr = do_row + IMG;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int j = blockIdx.x;  // key block
+    const int bg = blockIdx.y;
+    const int b = bg / P.G, g = bg % P.G;
+    const int h = P.h, RPT = 16 / h;  // query rows per column tile
+    const int key0 = 64 * j;
+    const T *Kb = (const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg;
+    const T *Vb = (const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg;
+    const float c2 = P.scale * LOG2E;
+
+    // ---- K_j, V_j -> LDS (row images); rows past S_kv re-read the last row (never covered by a mask)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = tid + 256 * i, r = p >> 3, pc = p & 7;
+        const int64_t kr = min(key0 + r, P.S_kv - 1);
+        *(u32x4 *)(k_img + off_row_img(r, pc)) = *(const u32x4 *)(Kb + kr * P.kss + pc * 8);
+        *(u32x4 *)(v_img + off_row_img(r, pc)) = *(const u32x4 *)(Vb + kr * P.vss + pc * 8);
+    }
+    __syncthreads();
+    // B operands of S = Q.K^T and dP = dO.V^T for this wave's 16 keys: loop invariant
+    x8 kB[2], vB[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        kB[s] = *(const x8 *)(k_img + off_row_img(16 * wave + rho, 4 * s + q));
+        vB[s] = *(const x8 *)(v_img + off_row_img(16 * wave + rho, 4 * s + q));
+    }
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        dK[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dV[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    uint32_t rd_row[2], rd_tr[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rd_row[s] = off_row_img(rho, 4 * s + q);
+    {
+        const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) rd_tr[n] = r * BROWB + ((n ^ bswz_tr(r)) << 5) + 8 * pp;
+    }
+
+    for (int base = 0; base < P.S; base += 256) {
+        // ---- scan 256 query rows: which of them selected keys of this block (lane = row)
+        const int t = base + tid;
+        unsigned long long mask = 0ull;
+        if (t < P.S) {
+            const int32_t *rg = P.ranges + (((int64_t)b * P.S + t) * P.G + g) * (int64_t)P.n * 2;
+            for (int i = 0; i < P.n; ++i) {
+                int s0 = min(max(rg[2 * i], 0), P.S_kv), e0 = min(max(rg[2 * i + 1], 0), P.S_kv);
+                const int lo = max(s0, key0) - key0, hi = min(e0, key0 + 64) - key0;
+                if (hi > lo) mask |= ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+            }
+        }
+        const unsigned long long hitb = __ballot(mask != 0ull);
+        if (lane == 0) s_cnt[wave] = __popcll(hitb);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_cnt[w];
+        const int nhit = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (mask != 0ull) {
+            const int pos = off + __popcll(hitb & ((1ull << lane) - 1ull));
+            s_t[pos] = t;
+            s_m[pos] = mask;
+        }
+        __syncthreads();
+
+        // ---- process the hit rows, KB_NCT column tiles (= KB_NCT*RPT rows) per staging round
+        const int rows_per_round = KB_NCT * RPT;
+        for (int r0 = 0; r0 < nhit; r0 += rows_per_round) {
+            // stage Q and dO rows of every slot twice (row image + transposable image), plus lse / delta / mask per slot
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
+                const int ct = slot >> 4, sl = slot & 15, qi = sl / h, hh = sl % h;
+                const int li = r0 + ct * RPT + qi;
+                u32x4 qa = {0u, 0u, 0u, 0u}, da = {0u, 0u, 0u, 0u};
+                if (qi < RPT && li < nhit) {
+                    const int64_t rrow = ((int64_t)b * P.S + s_t[li]) * P.G + g;
+                    qa = *(const u32x4 *)((const T *)P.Q + (rrow * h + hh) * (int64_t)BD + pc * 8);
+                    da = *(const u32x4 *)((const T *)P.dO + (rrow * h + hh) * (int64_t)BD + pc * 8);
+                }
+                *(u32x4 *)(q_row + off_row_img(slot, pc)) = qa;
+                *(u32x4 *)(q_tr + off_tr_img(slot, pc)) = qa;
+                *(u32x4 *)(do_row + off_row_img(slot, pc)) = da;
+                *(u32x4 *)(do_tr + off_tr_img(slot, pc)) = da;
+            }
+            if (tid < SLOTS) {
+                const int ct = tid >> 4, sl = tid & 15, qi = sl / h, hh = sl % h;
+                const int li = r0 + ct * RPT + qi;
+                float l2 = 0.f, dl = 0.f;
+                unsigned long long mk = 0ull;
+                if (qi < RPT && li < nhit) {
+                    const int64_t rrow = ((int64_t)b * P.S + s_t[li]) * P.G + g;
+                    l2 = P.lse[rrow * h + hh] * LOG2E;
+                    dl = delta[rrow * h + hh];
+                    mk = s_m[li];
+                }
+                s_lse2[tid] = l2;
+                s_delta[tid] = dl;
+                s_mask[tid] = mk;
+            }
+            __syncthreads();
+            const int ntile = min(KB_NCT, (nhit - r0 + RPT - 1) / RPT);
+            for (int ct = 0; ct < ntile; ++ct) {
+                const int sbase = 16 * ct;
+                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    S = M::mma32(*(const x8 *)(q_row + rd_row[s] + sbase * BROWB), kB[s], S);
+                    dP = M::mma32(*(const x8 *)(do_row + rd_row[s] + sbase * BROWB), vB[s], dP);
+                }
+                // accumulator rows = slots sbase + 4q + r, column = key 16 wave + rho
+                const f32x4 l2 = *(const f32x4 *)(s_lse2 + sbase + 4 * q);
+                const f32x4 dl = *(const f32x4 *)(s_delta + sbase + 4 * q);
+                x4 pa, dsa;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool cov = (s_mask[sbase + 4 * q + r] >> (16 * wave + rho)) & 1ull;
+                    const float p = cov ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r])) : 0.f;
+                    pa[r] = Elt<T>::from_f(p);
+                    dsa[r] = Elt<T>::from_f(p * (dP[r] - dl[r]) * P.scale);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    dV[n] = M::mma16(pa, tr_read<x4>(do_tr + rd_tr[n] + sbase * BROWB), dV[n]);
+                    dK[n] = M::mma16(dsa, tr_read<x4>(q_tr + rd_tr[n] + sbase * BROWB), dK[n]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- write this wave's 16 keys: accumulator rows = key 16 wave + 4q + r, column = d 16 n + rho
+    float *dKb = P.dK + ((int64_t)bg * P.S_kv) * BD;
+    float *dVb = P.dV + ((int64_t)bg * P.S_kv) * BD;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = key0 + 16 * wave + 4 * q + r;
+        if (key < P.S_kv) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                dKb[(int64_t)key * BD + 16 * n + rho] = dK[n][r];
+                dVb[(int64_t)key * BD + 16 * n + rho] = dV[n][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv) {
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
+}
+
+size_t sel_attn_bwd_mfma_workspace(int64_t R, int h) { return sizeof(float) * (size_t)R * h; }
+
+template <typename T>
+static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st) {
+    const int64_t nrh = P.R * P.h;
+    hipLaunchKernelGGL(bwd_delta_kernel<T>, dim3((unsigned)((nrh + 255) / 256)), dim3(256), 0, st, (const T *)P.O, (const T *)P.dO, delta,
+                       nrh, P.Dv);
+    NSA_LAUNCH_CHECK("bwd_delta");
+    int map_mode = 0;
+    unsigned grid = (unsigned)((P.R + 3) / 4);
+    if (P.S >= 16) {
+        const int64_t nbg = P.R / P.S, W = (P.S + 3) / 4;
+        if (nbg * W < ((int64_t)1 << 31)) {
+            map_mode = (nbg % 8 == 0) ? 2 : 1;
+            grid = (unsigned)(nbg * W);
+        }
+    }
+    constexpr size_t lds = 4 * (3 * 32 * BROWB + ((SEG_INTS * 4 + 15) / 16) * 16);
+    hipLaunchKernelGGL(bwd_dq_kernel<T>, dim3(grid), dim3(256), lds, st, P, (const float *)delta, map_mode);
+    NSA_LAUNCH_CHECK("bwd_dq");
+    const int64_t nbg = (int64_t)(P.R / P.S);
+    NSA_CHECK_ARG(nbg <= 65535, "bwd: B*G too large for one launch");
+    hipLaunchKernelGGL(bwd_dkdv_kernel<T>, dim3((unsigned)((P.S_kv + 63) / 64), (unsigned)nbg), dim3(256), 0, st, P, (const float *)delta);
+    NSA_LAUNCH_CHECK("bwd_dkdv");
+    return NSA_OK;
+}
+
+int launch_sel_attn_bwd_mfma(const SelAttnBwdParams &P, int dtype, float *delta_ws, hipStream_t st) {
+    NSA_CHECK_ARG(sel_attn_bwd_mfma_supported(dtype, P.h, P.Dk, P.Dv), "bwd MFMA: unsupported dtype/h/D");
+    NSA_CHECK_ARG(P.kss % 8 == 0 && P.vss % 8 == 0 && P.ksb % 8 == 0 && P.vsb % 8 == 0 && P.ksg % 8 == 0 && P.vsg % 8 == 0,
+                  "bwd MFMA: K/V strides must be multiples of 8 elements");
+    NSA_CHECK_ARG((int64_t)P.S_kv * P.kss * 2 < ((int64_t)1 << 31) && (int64_t)P.S_kv * P.vss * 2 < ((int64_t)1 << 31),
+                  "bwd MFMA: one (b,g) K/V slab must be smaller than 2 GiB");
+    if (dtype == NSA_DT_BF16) return launch_bwd_t<__bf16>(P, delta_ws, st);
+    return launch_bwd_t<_Float16>(P, delta_ws, st);
+}
+
+}  // namespace nsa

@@ -70,6 +70,7 @@ class _SelAttnFn(torch.autograd.Function):
         O, lse, (Qc, Kc, Vc, rg) = _fwd(Q, K, V, ranges, scale, variant, True)
         ctx.save_for_backward(Qc, Kc, Vc, rg, O, lse)
         ctx.scale = scale
+        ctx.bwd_variant = 0 if variant != 1 else 1  # variant 1 keeps the generic kernels on both passes
         return O
 
     @staticmethod
@@ -82,11 +83,14 @@ class _SelAttnFn(torch.autograd.Function):
         dQ = torch.empty_like(Qc)
         dK = torch.empty((B, G, S_kv, Dk), dtype=torch.float32, device=dev)
         dV = torch.empty((B, G, S_kv, Dv), dtype=torch.float32, device=dev)
-        rc = _lib.lib().nsa_sel_attn_bwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(),
-                                         lse.data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                                         B, S, G, h, Dk, Dv, S_kv, rg.shape[3],
-                                         Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
-                                         _DT[Qc.dtype], float(ctx.scale) if ctx.scale else 0.0, _stream(dev))
+        L = _lib.lib()
+        ws = workspace(dev, L.nsa_sel_attn_bwd_workspace(B, S, G, h, Dk, Dv, _DT[Qc.dtype], ctx.bwd_variant), "attn_bwd")
+        rc = L.nsa_sel_attn_bwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(),
+                                lse.data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                                B, S, G, h, Dk, Dv, S_kv, rg.shape[3],
+                                Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
+                                _DT[Qc.dtype], float(ctx.scale) if ctx.scale else 0.0, int(ctx.bwd_variant),
+                                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
         _lib.check(rc, "nsa_sel_attn_bwd")
         return dQ, dK.to(Kc.dtype), dV.to(Vc.dtype), None, None, None
 

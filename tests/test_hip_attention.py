@@ -245,6 +245,38 @@ def test_backward_m7c_shape_bf16(nv, orc):
         assert np.abs(got.float().cpu().numpy() - ref).max() <= 6e-2 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,S,G,h,S_kv,n,aligned", [(1, 6, 2, 6, 512, 5, True), (2, 300, 2, 6, 300, 6, False), (1, 700, 1, 16, 700, 4, True),
+                                                   (2, 40, 2, 1, 130, 3, False), (1, 520, 2, 4, 520, 16, True)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_backward_mfma_vs_oracle(nv, orc, B, S, G, h, S_kv, n, aligned, dtype):
+    """MFMA backward (dQ query-major, dK/dV key-block-major, no atomics) vs the oracle's fp64 backward; also against the
+    generic kernel, and bitwise run-to-run reproducibility."""
+    rng = np.random.default_rng([B, S, h, n])
+    D = 64
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    dO = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv, aligned=aligned)
+    rg[0, 0, 0] = 0  # empty row
+    rg[0, 1, 0, 0] = (0, S_kv)  # everything, overlapping the other ranges of the row
+    grads = []
+    for rep in range(2):
+        q, k, v = (dev(x, dtype).requires_grad_(True) for x in (Q, K, V))
+        nv.selection_attention_hip(q, k, v, dev(rg), variant=2).backward(dev(dO, dtype))
+        grads.append((q.grad, k.grad, v.grad))
+    for a, b_ in zip(grads[0], grads[1]):
+        assert torch.equal(a, b_)  # no atomics: bitwise reproducible
+    rq, rk, rv = orc.sel_attention_masked_bwd(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), rg, rounded(dO, dtype))
+    for got, ref, name in zip(grads[0], (rq, rk, rv), ("dQ", "dK", "dV")):
+        err = np.abs(got.float().cpu().numpy() - ref).max()
+        assert err <= 3e-2 * max(1.0, np.abs(ref).max()), f"{name} err {err:.3e} (ref max {np.abs(ref).max():.2f})"
+    q, k, v = (dev(x, dtype).requires_grad_(True) for x in (Q, K, V))
+    nv.selection_attention_hip(q, k, v, dev(rg), variant=1).backward(dev(dO, dtype))
+    for got, gen in zip(grads[0], (q.grad, k.grad, v.grad)):
+        assert (got.float() - gen.float()).abs().max().item() <= 3e-2 * max(1.0, gen.float().abs().max().item())
+
+
 def test_properties_full_size_64k(nv):
     """Size-independent properties at the BASELINE full size (S=65536, m7c, bf16, every row)."""
     torch.manual_seed(0)
