@@ -92,8 +92,9 @@ NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const 
  * O and lse come from the forward.
  *   variant 0 auto, 1 generic (any dtype/shape: one wave per query row, dK/dV by fp32 atomics),
  *   2 MFMA (bf16/f16, Dk = Dv = 64, h <= 16): dQ query-major + dK/dV key-block-major, no atomics, reproducible.
- *   workspace: nsa_sel_attn_bwd_workspace() bytes (B*S*G*h floats for the MFMA route, else 0). */
-NSA_API size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int variant);
+ *   workspace: nsa_sel_attn_bwd_workspace() bytes (MFMA route: B*S*G*h floats for rowsum(dO*O) plus, when the query
+ *   rows are split over workgroups, the per-split dK/dV partial sums that are added in fixed order; else 0). */
+NSA_API size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant);
 NSA_API int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t *ranges, const void *O,
                      const float *lse, const void *dO, void *dQ, float *dK, float *dV, int B, int S,
                      int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t k_stride_b,

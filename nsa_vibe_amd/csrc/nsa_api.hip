@@ -129,9 +129,9 @@ int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t 
     return launch_sel_attn_fwd_generic(P, dtype, st);
 }
 
-size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int variant) {
+size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant) {
     if (variant == 1 || !sel_attn_bwd_mfma_supported(dtype, h, Dk, Dv)) return 0;
-    return sel_attn_bwd_mfma_workspace((int64_t)B * S * G, h);
+    return sel_attn_bwd_mfma_workspace((int64_t)B * S * G, h, S, (int64_t)B * G, S_kv);
 }
 
 int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t *ranges, const void *O,
@@ -152,7 +152,7 @@ int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t 
     const bool fast_ok = !empty && sel_attn_bwd_mfma_supported(dtype, h, Dk, Dv) && kss % 8 == 0 && vss % 8 == 0 && ksb % 8 == 0 &&
                          vsb % 8 == 0 && ksg % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) &&
                          ((uintptr_t)V % 16 == 0) && ((uintptr_t)dO % 16 == 0) && ((uintptr_t)O % 16 == 0) && (int64_t)B * G <= 65535 &&
-                         workspace && workspace_bytes >= sel_attn_bwd_mfma_workspace(R, h) && ((uintptr_t)workspace % 4 == 0);
+                         workspace && workspace_bytes >= sel_attn_bwd_mfma_workspace(R, h, S, (int64_t)B * G, S_kv) && ((uintptr_t)workspace % 16 == 0);
     if (variant == 2) NSA_CHECK_ARG(fast_ok, "sel_attn_bwd: MFMA variant requested but shape/dtype/alignment/workspace unsupported");
     const bool fast = fast_ok && variant != 1;
     if (!fast && (int64_t)B * G * S_kv > 0) {  // the generic kernel accumulates with atomics; the MFMA route writes every element

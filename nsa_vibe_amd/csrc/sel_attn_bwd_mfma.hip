@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(SelAttnBwdParams P, const f
 constexpr int KB_NCT = 4;  // column tiles (of 16 (query,head) slots) staged per round
 
 template <typename T>
-__global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta) {
+__global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta, float *__restrict__ part,
+                                                        int rows_per_split) {
     using M = BwdT<T>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
@@ -327,11 +328,15 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         for (int n = 0; n < 4; ++n) rd_tr[n] = r * BROWB + ((n ^ bswz_tr(r)) << 5) + 8 * pp;
     }
 
-    for (int base = 0; base < P.S; base += 256) {
+    // query rows are split over gridDim.z workgroups per key block (block 0 and the local blocks are selected by every
+    // row: without the split their workgroups are a long serial tail); the partial sums are added by a second kernel
+    // in fixed order, so the result stays bitwise reproducible
+    const int row_begin = blockIdx.z * rows_per_split, row_end = min(P.S, row_begin + rows_per_split);
+    for (int base = row_begin; base < row_end; base += 256) {
         // ---- scan 256 query rows: which of them selected keys of this block (lane = row)
         const int t = base + tid;
         unsigned long long mask = 0ull;
-        if (t < P.S) {
+        if (t < row_end) {
             const int32_t *rg = P.ranges + (((int64_t)b * P.S + t) * P.G + g) * (int64_t)P.n * 2;
             for (int i = 0; i < P.n; ++i) {
                 int s0 = min(max(rg[2 * i], 0), P.S_kv), e0 = min(max(rg[2 * i + 1], 0), P.S_kv);
@@ -352,41 +357,57 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         }
         __syncthreads();
 
-        // ---- process the hit rows, KB_NCT column tiles (= KB_NCT*RPT rows) per staging round
+        // ---- process the hit rows, KB_NCT column tiles (= KB_NCT*RPT rows) per staging round.  The global loads of
+        // round r+1 (Q, dO rows, lse, delta) are issued into registers before the MFMAs of round r.
         const int rows_per_round = KB_NCT * RPT;
-        for (int r0 = 0; r0 < nhit; r0 += rows_per_round) {
-            // stage Q and dO rows of every slot twice (row image + transposable image), plus lse / delta / mask per slot
+        u32x4 qa[2], da[2];
+        float l2n = 0.f, dln = 0.f;
+        unsigned long long mkn = 0ull;
+        auto fetch_round = [&](int r0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
                 const int ct = slot >> 4, sl = slot & 15, qi = sl / h, hh = sl % h;
                 const int li = r0 + ct * RPT + qi;
-                u32x4 qa = {0u, 0u, 0u, 0u}, da = {0u, 0u, 0u, 0u};
+                qa[i] = (u32x4){0u, 0u, 0u, 0u};
+                da[i] = (u32x4){0u, 0u, 0u, 0u};
                 if (qi < RPT && li < nhit) {
                     const int64_t rrow = ((int64_t)b * P.S + s_t[li]) * P.G + g;
-                    qa = *(const u32x4 *)((const T *)P.Q + (rrow * h + hh) * (int64_t)BD + pc * 8);
-                    da = *(const u32x4 *)((const T *)P.dO + (rrow * h + hh) * (int64_t)BD + pc * 8);
+                    qa[i] = *(const u32x4 *)((const T *)P.Q + (rrow * h + hh) * (int64_t)BD + pc * 8);
+                    da[i] = *(const u32x4 *)((const T *)P.dO + (rrow * h + hh) * (int64_t)BD + pc * 8);
                 }
-                *(u32x4 *)(q_row + off_row_img(slot, pc)) = qa;
-                *(u32x4 *)(q_tr + off_tr_img(slot, pc)) = qa;
-                *(u32x4 *)(do_row + off_row_img(slot, pc)) = da;
-                *(u32x4 *)(do_tr + off_tr_img(slot, pc)) = da;
             }
+            l2n = 0.f;
+            dln = 0.f;
+            mkn = 0ull;
             if (tid < SLOTS) {
                 const int ct = tid >> 4, sl = tid & 15, qi = sl / h, hh = sl % h;
                 const int li = r0 + ct * RPT + qi;
-                float l2 = 0.f, dl = 0.f;
-                unsigned long long mk = 0ull;
                 if (qi < RPT && li < nhit) {
                     const int64_t rrow = ((int64_t)b * P.S + s_t[li]) * P.G + g;
-                    l2 = P.lse[rrow * h + hh] * LOG2E;
-                    dl = delta[rrow * h + hh];
-                    mk = s_m[li];
+                    l2n = P.lse[rrow * h + hh] * LOG2E;
+                    dln = delta[rrow * h + hh];
+                    mkn = s_m[li];
                 }
-                s_lse2[tid] = l2;
-                s_delta[tid] = dl;
-                s_mask[tid] = mk;
             }
+        };
+        if (nhit > 0) fetch_round(0);
+        for (int r0 = 0; r0 < nhit; r0 += rows_per_round) {
+            // stage Q and dO rows of every slot twice (row image + transposable image), plus lse / delta / mask per slot
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
+                *(u32x4 *)(q_row + off_row_img(slot, pc)) = qa[i];
+                *(u32x4 *)(q_tr + off_tr_img(slot, pc)) = qa[i];
+                *(u32x4 *)(do_row + off_row_img(slot, pc)) = da[i];
+                *(u32x4 *)(do_tr + off_tr_img(slot, pc)) = da[i];
+            }
+            if (tid < SLOTS) {
+                s_lse2[tid] = l2n;
+                s_delta[tid] = dln;
+                s_mask[tid] = mkn;
+            }
+            if (r0 + rows_per_round < nhit) fetch_round(r0 + rows_per_round);
             __syncthreads();
             const int ntile = min(KB_NCT, (nhit - r0 + RPT - 1) / RPT);
             for (int ct = 0; ct < ntile; ++ct) {
@@ -418,8 +439,9 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         }
     }
     // ---- write this wave's 16 keys: accumulator rows = key 16 wave + 4q + r, column = d 16 n + rho
-    float *dKb = P.dK + ((int64_t)bg * P.S_kv) * BD;
-    float *dVb = P.dV + ((int64_t)bg * P.S_kv) * BD;
+    const int64_t slab = (int64_t)gridDim.y * P.S_kv * BD;  // floats of one [B*G,S_kv,D] tensor
+    float *dKb = (gridDim.z > 1 ? part + (int64_t)blockIdx.z * 2 * slab : P.dK) + ((int64_t)bg * P.S_kv) * BD;
+    float *dVb = (gridDim.z > 1 ? part + (int64_t)blockIdx.z * 2 * slab + slab : P.dV) + ((int64_t)bg * P.S_kv) * BD;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int key = key0 + 16 * wave + 4 * q + r;
@@ -433,12 +455,33 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     }
 }
 
+// sum the row-split partials [ns][2][slab] into dK / dV in ascending split order
+__global__ __launch_bounds__(256) void bwd_reduce_kernel(const float *__restrict__ part, float *__restrict__ dK, float *__restrict__ dV,
+                                                          int64_t slab, int ns) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= 2 * slab) return;
+    f32x4 acc = *(const f32x4 *)(part + i);
+    for (int z = 1; z < ns; ++z) acc += *(const f32x4 *)(part + (int64_t)z * 2 * slab + i);
+    float *dst = i < slab ? dK + i : dV + (i - slab);
+    *(f32x4 *)dst = acc;
+}
+
 // ------------------------------------------------------------------------------------------ host
+static int dkdv_splits(int S) {
+    int ns = (S + 511) / 512;
+    return ns < 1 ? 1 : (ns > 16 ? 16 : ns);
+}
+
 bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv) {
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
 }
 
-size_t sel_attn_bwd_mfma_workspace(int64_t R, int h) { return sizeof(float) * (size_t)R * h; }
+// delta [R*h] floats, then (when the rows are split) ns partial [dK|dV] slabs
+size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_kv) {
+    const int ns = dkdv_splits(S);
+    const size_t d = (sizeof(float) * (size_t)R * h + 15) & ~(size_t)15;
+    return d + (ns > 1 ? sizeof(float) * (size_t)ns * 2 * (size_t)nbg * S_kv * BD : 0);
+}
 
 template <typename T>
 static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st) {
@@ -460,8 +503,18 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
     NSA_LAUNCH_CHECK("bwd_dq");
     const int64_t nbg = (int64_t)(P.R / P.S);
     NSA_CHECK_ARG(nbg <= 65535, "bwd: B*G too large for one launch");
-    hipLaunchKernelGGL(bwd_dkdv_kernel<T>, dim3((unsigned)((P.S_kv + 63) / 64), (unsigned)nbg), dim3(256), 0, st, P, (const float *)delta);
+    const int ns = dkdv_splits(P.S);
+    const int rows_per_split = ((P.S + ns - 1) / ns + 255) / 256 * 256;
+    float *part = (float *)((unsigned char *)delta + ((sizeof(float) * (size_t)P.R * P.h + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(bwd_dkdv_kernel<T>, dim3((unsigned)((P.S_kv + 63) / 64), (unsigned)nbg, (unsigned)ns), dim3(256), 0, st, P,
+                       (const float *)delta, part, rows_per_split);
     NSA_LAUNCH_CHECK("bwd_dkdv");
+    if (ns > 1) {
+        const int64_t slab = nbg * P.S_kv * BD;
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((2 * slab / 4 + 255) / 256)), dim3(256), 0, st, (const float *)part, P.dK, P.dV,
+                           slab, ns);
+        NSA_LAUNCH_CHECK("bwd_reduce");
+    }
     return NSA_OK;
 }
 

@@ -43,7 +43,7 @@ bool sel_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
 int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st);
 size_t sel_attn_mfma_workspace(int64_t R, int h, int Dv, int *nsplit_out);
 bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv);
-size_t sel_attn_bwd_mfma_workspace(int64_t R, int h);
+size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_kv);
 int launch_sel_attn_bwd_mfma(const SelAttnBwdParams &P, int dtype, float *delta_ws, hipStream_t st);
 
 }  // namespace nsa

@@ -84,7 +84,7 @@ class _SelAttnFn(torch.autograd.Function):
         dK = torch.empty((B, G, S_kv, Dk), dtype=torch.float32, device=dev)
         dV = torch.empty((B, G, S_kv, Dv), dtype=torch.float32, device=dev)
         L = _lib.lib()
-        ws = workspace(dev, L.nsa_sel_attn_bwd_workspace(B, S, G, h, Dk, Dv, _DT[Qc.dtype], ctx.bwd_variant), "attn_bwd")
+        ws = workspace(dev, L.nsa_sel_attn_bwd_workspace(B, S, G, h, Dk, Dv, S_kv, _DT[Qc.dtype], ctx.bwd_variant), "attn_bwd")
         rc = L.nsa_sel_attn_bwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(),
                                 lse.data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
                                 B, S, G, h, Dk, Dv, S_kv, rg.shape[3],
