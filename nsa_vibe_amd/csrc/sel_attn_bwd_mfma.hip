@@ -267,29 +267,47 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(SelAttnBwdParams P, const f
 }
 
 // ------------------------------------------------------------------------------------------ 3. dK / dV (key-block-major)
-constexpr int KB_NCT = 4;  // column tiles (of 16 (query,head) slots) staged per round
+constexpr int KB_NCT = 8;
+#ifdef NSA_DBG_WGTIME
+__device__ unsigned long long g_dbg[4 * 65536];
+#endif  // column tiles (of 16 (query,head) slots) staged per round
 
 template <typename T>
 __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta, float *__restrict__ part,
-                                                        int rows_per_split) {
+                                                        const unsigned long long *__restrict__ hitmap, int *__restrict__ flags,
+                                                        int rows_per_split, int nkb, int nbg, int nsplit) {
     using M = BwdT<T>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
+    // Workgroup -> (key block j, bg, row split z).  Workgroups go round-robin over the 8 XCDs by linear id; all key blocks
+    // of one (bg, z) pair are put on ONE XCD (its 512 Q/dO rows stay in that L2), and the pairs are dealt evenly over the
+    // XCDs (every pair carries about the same number of hits, while key block 0 alone is hit by every row: a j-major
+    // order leaves one XCD with several times the work of the others).
+    int j, bg, zsp;
+    {
+        const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
+        const int pair = (slot / nkb) * 8 + xcd;
+        j = slot % nkb;
+        if (pair >= nbg * nsplit) return;
+        zsp = pair / nbg;
+        bg = pair - zsp * nbg;
+    }
     constexpr int SLOTS = 16 * KB_NCT;        // (query,head) slots per round
-    constexpr int IMG = SLOTS * BROWB;        // 8 KiB
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * BROWB + 4 * IMG];
+    constexpr int IMG = SLOTS * BROWB;        // bytes of one staged image
+    constexpr int NLD = SLOTS * 8 / 256;      // 16-byte pieces per thread and image
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * IMG];  // the K/V block images alias the staging images (only read before the loop)
     __shared__ __attribute__((aligned(16))) float s_lse2[SLOTS], s_delta[SLOTS];
     __shared__ __attribute__((aligned(16))) unsigned long long s_mask[SLOTS];
     __shared__ int s_t[256];
     __shared__ unsigned long long s_m[256];
-    __shared__ int s_cnt[5];
     unsigned char *k_img = lds, *v_img = lds + 64 * BROWB;
-    unsigned char *q_row = lds + 2 * 64 * BROWB, *q_tr = q_row + IMG, *do_row = q_tr + IMG, *do_tr = do_row + IMG;
+    unsigned char *q_row = lds, *q_tr = q_row + IMG, *do_row = q_tr + IMG, *do_tr = do_row + IMG;
 
+#ifdef NSA_DBG_WGTIME
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int rho = lane & 15, q = lane >> 4;
-    const int j = blockIdx.x;  // key block
-    const int bg = blockIdx.y;
     const int b = bg / P.G, g = bg % P.G;
     const int h = P.h, RPT = 16 / h;  // query rows per column tile
     const int key0 = 64 * j;
@@ -313,6 +331,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         kB[s] = *(const x8 *)(k_img + off_row_img(16 * wave + rho, 4 * s + q));
         vB[s] = *(const x8 *)(v_img + off_row_img(16 * wave + rho, 4 * s + q));
     }
+    __syncthreads();
     f32x4 dK[4], dV[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -331,26 +350,37 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     // query rows are split over gridDim.z workgroups per key block (block 0 and the local blocks are selected by every
     // row: without the split their workgroups are a long serial tail); the partial sums are added by a second kernel
     // in fixed order, so the result stays bitwise reproducible
-    const int row_begin = blockIdx.z * rows_per_split, row_end = min(P.S, row_begin + rows_per_split);
+    const int row_begin = zsp * rows_per_split, row_end = min(P.S, row_begin + rows_per_split);
+    const int wpb = (P.S + 63) >> 6;  // hit-map words per (bg, key block)
+    const unsigned long long *hm = hitmap + ((int64_t)bg * nkb + j) * wpb;
+    int total_hits = 0;
     for (int base = row_begin; base < row_end; base += 256) {
-        // ---- scan 256 query rows: which of them selected keys of this block (lane = row)
-        const int t = base + tid;
-        unsigned long long mask = 0ull;
-        if (t < row_end) {
+        // ---- which of these 256 query rows selected keys of this block: 4 words of the hit map (lane = row)
+        unsigned long long hw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int wi = (base >> 6) + w;
+            hw[w] = wi < wpb ? hm[wi] : 0ull;
+        }
+        const int nhit = __popcll(hw[0]) + __popcll(hw[1]) + __popcll(hw[2]) + __popcll(hw[3]);
+        if (nhit == 0) continue;  // uniform over the workgroup
+        total_hits += nhit;
+        int off = 0;
+        unsigned long long hitb = 0ull;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) off += __popcll(hw[w]);
+            if (w == wave) hitb = hw[w];
+        }
+        if ((hitb >> lane) & 1ull) {
+            const int t = base + tid;
+            unsigned long long mask = 0ull;
             const int32_t *rg = P.ranges + (((int64_t)b * P.S + t) * P.G + g) * (int64_t)P.n * 2;
             for (int i = 0; i < P.n; ++i) {
                 int s0 = min(max(rg[2 * i], 0), P.S_kv), e0 = min(max(rg[2 * i + 1], 0), P.S_kv);
                 const int lo = max(s0, key0) - key0, hi = min(e0, key0 + 64) - key0;
                 if (hi > lo) mask |= ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
             }
-        }
-        const unsigned long long hitb = __ballot(mask != 0ull);
-        if (lane == 0) s_cnt[wave] = __popcll(hitb);
-        __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; ++w) off += s_cnt[w];
-        const int nhit = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (mask != 0ull) {
             const int pos = off + __popcll(hitb & ((1ull << lane) - 1ull));
             s_t[pos] = t;
             s_m[pos] = mask;
@@ -360,12 +390,12 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         // ---- process the hit rows, KB_NCT column tiles (= KB_NCT*RPT rows) per staging round.  The global loads of
         // round r+1 (Q, dO rows, lse, delta) are issued into registers before the MFMAs of round r.
         const int rows_per_round = KB_NCT * RPT;
-        u32x4 qa[2], da[2];
+        u32x4 qa[NLD], da[NLD];
         float l2n = 0.f, dln = 0.f;
         unsigned long long mkn = 0ull;
         auto fetch_round = [&](int r0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NLD; ++i) {
                 const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
                 const int ct = slot >> 4, sl = slot & 15, qi = sl / h, hh = sl % h;
                 const int li = r0 + ct * RPT + qi;
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         for (int r0 = 0; r0 < nhit; r0 += rows_per_round) {
             // stage Q and dO rows of every slot twice (row image + transposable image), plus lse / delta / mask per slot
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NLD; ++i) {
                 const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
                 *(u32x4 *)(q_row + off_row_img(slot, pc)) = qa[i];
                 *(u32x4 *)(q_tr + off_tr_img(slot, pc)) = qa[i];
@@ -438,10 +468,28 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
             __syncthreads();
         }
     }
-    // ---- write this wave's 16 keys: accumulator rows = key 16 wave + 4q + r, column = d 16 n + rho
-    const int64_t slab = (int64_t)gridDim.y * P.S_kv * BD;  // floats of one [B*G,S_kv,D] tensor
-    float *dKb = (gridDim.z > 1 ? part + (int64_t)blockIdx.z * 2 * slab : P.dK) + ((int64_t)bg * P.S_kv) * BD;
-    float *dVb = (gridDim.z > 1 ? part + (int64_t)blockIdx.z * 2 * slab + slab : P.dV) + ((int64_t)bg * P.S_kv) * BD;
+    // ---- write this wave's 16 keys: accumulator rows = key 16 wave + 4q + r, column = d 16 n + rho.  A split without
+    // hits writes nothing and says so in flags[] (the reduce kernel skips it).
+#ifdef NSA_DBG_WGTIME
+    if (tid == 0) {
+        const int64_t w = ((int64_t)zsp * nbg + bg) * nkb + j;
+        if (w < 65536) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hwid));
+            g_dbg[4 * w] = dbg_t0;
+            g_dbg[4 * w + 1] = wall_clock64();
+            g_dbg[4 * w + 2] = total_hits;
+            g_dbg[4 * w + 3] = hwid;
+        }
+    }
+#endif
+    if (nsplit > 1) {
+        if (tid == 0) flags[((int64_t)zsp * nbg + bg) * nkb + j] = total_hits > 0;
+        if (total_hits == 0) return;
+    }
+    const int64_t slab = (int64_t)nbg * P.S_kv * BD;  // floats of one [B*G,S_kv,D] tensor
+    float *dKb = (nsplit > 1 ? part + (int64_t)zsp * 2 * slab : P.dK) + ((int64_t)bg * P.S_kv) * BD;
+    float *dVb = (nsplit > 1 ? part + (int64_t)zsp * 2 * slab + slab : P.dV) + ((int64_t)bg * P.S_kv) * BD;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int key = key0 + 16 * wave + 4 * q + r;
@@ -455,15 +503,52 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     }
 }
 
-// sum the row-split partials [ns][2][slab] into dK / dV in ascending split order
-__global__ __launch_bounds__(256) void bwd_reduce_kernel(const float *__restrict__ part, float *__restrict__ dK, float *__restrict__ dV,
-                                                          int64_t slab, int ns) {
+// sum the row-split partials [ns][2][slab] into dK / dV in ascending split order (splits without hits are skipped)
+__global__ __launch_bounds__(256) void bwd_reduce_kernel(const float *__restrict__ part, const int *__restrict__ flags,
+                                                          float *__restrict__ dK, float *__restrict__ dV, int64_t slab, int ns, int S_kv,
+                                                          int nkb) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= 2 * slab) return;
-    f32x4 acc = *(const f32x4 *)(part + i);
-    for (int z = 1; z < ns; ++z) acc += *(const f32x4 *)(part + (int64_t)z * 2 * slab + i);
+    const int64_t e = i < slab ? i : i - slab;
+    const int64_t krow = e / BD, bg = krow / S_kv;
+    const int jb = (int)(krow - bg * S_kv) >> 6;
+    const int64_t nfl = slab / BD / S_kv * nkb;  // flags per split
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ns; ++z)
+        if (flags[z * nfl + bg * nkb + jb]) acc += *(const f32x4 *)(part + (int64_t)z * 2 * slab + i);
     float *dst = i < slab ? dK + i : dV + (i - slab);
     *(f32x4 *)dst = acc;
+}
+
+// Inverted index of the selection: hitmap[bg][key block j][t / 64] bit (t % 64) = row t of (b,g) has a range reaching into
+// keys [64 j, 64 j + 64).  One wave = the 64 rows of one word: lanes that reach the same block are gathered with a ballot, so
+// a word gets one OR per (range slot, block) instead of one per row; OR-ing makes the result independent of the order.
+__global__ __launch_bounds__(256) void bwd_hitmap_kernel(const int32_t *__restrict__ ranges, unsigned long long *__restrict__ hitmap,
+                                                          int64_t nwords, int S, int G, int n, int S_kv, int nkb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwords) return;
+    const int wpb = (S + 63) >> 6;
+    const int64_t bg = wid / wpb;
+    const int tw = (int)(wid - bg * wpb), t = 64 * tw + lane;
+    const int64_t b = bg / G, g = bg - b * G;
+    const int32_t *rg = ranges + ((b * S + min(t, S - 1)) * G + g) * (int64_t)n * 2;
+    unsigned long long *w = hitmap + bg * nkb * wpb + tw;
+    for (int i = 0; i < n; ++i) {
+        const int s0 = min(max(rg[2 * i], 0), S_kv), e0 = min(max(rg[2 * i + 1], 0), S_kv);
+        int j = s0 >> 6;
+        const int jend = (t < S && e0 > s0) ? (e0 - 1) >> 6 : -1;
+        for (;;) {
+            const unsigned long long todo = __ballot(j <= jend);
+            if (todo == 0ull) break;
+            const int src = __ffsll((long long)todo) - 1;
+            const int j0 = __shfl(j, src);
+            const bool mine = j <= jend && j == j0;
+            const unsigned long long m = __ballot(mine);
+            if (lane == src) atomicOr(w + (int64_t)j0 * wpb, m);
+            if (mine) ++j;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -476,12 +561,24 @@ bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv) {
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
 }
 
-// delta [R*h] floats, then (when the rows are split) ns partial [dK|dV] slabs
-size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_kv) {
-    const int ns = dkdv_splits(S);
-    const size_t d = (sizeof(float) * (size_t)R * h + 15) & ~(size_t)15;
-    return d + (ns > 1 ? sizeof(float) * (size_t)ns * 2 * (size_t)nbg * S_kv * BD : 0);
+// workspace layout: delta [R*h] f32 | hit map [nbg][nkb][ceil(S/64)] u64 | flags [ns][nbg][nkb] i32 | ns partial [dK|dV] slabs
+struct BwdWs {
+    size_t hitmap, flags, part, total, hitmap_bytes;
+    int ns, nkb;
+};
+static BwdWs bwd_ws_layout(int64_t R, int h, int S, int64_t nbg, int S_kv) {
+    BwdWs w;
+    w.ns = dkdv_splits(S);
+    w.nkb = (S_kv + 63) / 64;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    w.hitmap = up(sizeof(float) * (size_t)R * h);
+    w.hitmap_bytes = sizeof(unsigned long long) * (size_t)nbg * w.nkb * ((S + 63) / 64);
+    w.flags = w.hitmap + up(w.hitmap_bytes);
+    w.part = w.flags + up(sizeof(int) * (size_t)w.ns * nbg * w.nkb);
+    w.total = w.part + (w.ns > 1 ? sizeof(float) * (size_t)w.ns * 2 * (size_t)nbg * S_kv * BD : 0);
+    return w;
 }
+size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_kv) { return bwd_ws_layout(R, h, S, nbg, S_kv).total; }
 
 template <typename T>
 static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st) {
@@ -503,21 +600,37 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
     NSA_LAUNCH_CHECK("bwd_dq");
     const int64_t nbg = (int64_t)(P.R / P.S);
     NSA_CHECK_ARG(nbg <= 65535, "bwd: B*G too large for one launch");
-    const int ns = dkdv_splits(P.S);
+    const BwdWs W = bwd_ws_layout(P.R, P.h, P.S, nbg, P.S_kv);
+    const int ns = W.ns;
     const int rows_per_split = ((P.S + ns - 1) / ns + 255) / 256 * 256;
-    float *part = (float *)((unsigned char *)delta + ((sizeof(float) * (size_t)P.R * P.h + 15) & ~(size_t)15));
-    hipLaunchKernelGGL(bwd_dkdv_kernel<T>, dim3((unsigned)((P.S_kv + 63) / 64), (unsigned)nbg, (unsigned)ns), dim3(256), 0, st, P,
-                       (const float *)delta, part, rows_per_split);
+    unsigned char *ws = (unsigned char *)delta;
+    unsigned long long *hitmap = (unsigned long long *)(ws + W.hitmap);
+    int *flags = (int *)(ws + W.flags);
+    float *part = (float *)(ws + W.part);
+    NSA_HIP_TRY(hipMemsetAsync(hitmap, 0, W.hitmap_bytes, st));
+    const int64_t nwords = nbg * ((P.S + 63) / 64);
+    hipLaunchKernelGGL(bwd_hitmap_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, st, P.ranges, hitmap, nwords, P.S, P.G, P.n,
+                       P.S_kv, W.nkb);
+    NSA_LAUNCH_CHECK("bwd_hitmap");
+    const int64_t ngrid = ((nbg * ns + 7) / 8) * 8 * W.nkb;
+    NSA_CHECK_ARG(ngrid < ((int64_t)1 << 31), "bwd: too many key-block workgroups for one launch");
+    hipLaunchKernelGGL(bwd_dkdv_kernel<T>, dim3((unsigned)ngrid), dim3(256), 0, st, P, (const float *)delta, part,
+                       (const unsigned long long *)hitmap, flags, rows_per_split, W.nkb, (int)nbg, ns);
     NSA_LAUNCH_CHECK("bwd_dkdv");
     if (ns > 1) {
         const int64_t slab = nbg * P.S_kv * BD;
-        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((2 * slab / 4 + 255) / 256)), dim3(256), 0, st, (const float *)part, P.dK, P.dV,
-                           slab, ns);
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((2 * slab / 4 + 255) / 256)), dim3(256), 0, st, (const float *)part,
+                           (const int *)flags, P.dK, P.dV, slab, ns, P.S_kv, W.nkb);
         NSA_LAUNCH_CHECK("bwd_reduce");
     }
     return NSA_OK;
 }
 
+#ifdef NSA_DBG_WGTIME
+extern "C" __attribute__((visibility("default"))) int nsa_dbg_read(void *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 4 * 65536);
+}
+#endif
 int launch_sel_attn_bwd_mfma(const SelAttnBwdParams &P, int dtype, float *delta_ws, hipStream_t st) {
     NSA_CHECK_ARG(sel_attn_bwd_mfma_supported(dtype, P.h, P.Dk, P.Dv), "bwd MFMA: unsupported dtype/h/D");
     NSA_CHECK_ARG(P.kss % 8 == 0 && P.vss % 8 == 0 && P.ksb % 8 == 0 && P.vsb % 8 == 0 && P.ksg % 8 == 0 && P.vsg % 8 == 0,
