@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * IMG];  // the K/V block images alias the staging images (only read before the loop)
     __shared__ __attribute__((aligned(16))) float s_lse2[SLOTS], s_delta[SLOTS];
     __shared__ __attribute__((aligned(16))) unsigned long long s_mask[SLOTS];
-    __shared__ int s_t[256];
-    __shared__ unsigned long long s_m[256];
+    __shared__ int s_t[512];
+    __shared__ unsigned long long s_m[512];
     unsigned char *k_img = lds, *v_img = lds + 64 * BROWB;
     unsigned char *q_row = lds, *q_tr = q_row + IMG, *do_row = q_tr + IMG, *do_tr = do_row + IMG;
 
@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     const int row_begin = zsp * rows_per_split, row_end = min(P.S, row_begin + rows_per_split);
     const int wpb = (P.S + 63) >> 6;  // hit-map words per (bg, key block)
     const unsigned long long *hm = hitmap + ((int64_t)bg * nkb + j) * wpb;
-    int total_hits = 0;
+    // Hits are collected over 256-row chunks until at least 256 are pending (far-away key blocks see a handful of hits per
+    // chunk at long context; staging rounds want to be full)
+    int total_hits = 0, pend = 0;
     for (int base = row_begin; base < row_end; base += 256) {
         // ---- which of these 256 query rows selected keys of this block: 4 words of the hit map (lane = row)
         unsigned long long hw[4];
@@ -362,10 +364,11 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
             const int wi = (base >> 6) + w;
             hw[w] = wi < wpb ? hm[wi] : 0ull;
         }
-        const int nhit = __popcll(hw[0]) + __popcll(hw[1]) + __popcll(hw[2]) + __popcll(hw[3]);
-        if (nhit == 0) continue;  // uniform over the workgroup
-        total_hits += nhit;
-        int off = 0;
+        const int nnew = __popcll(hw[0]) + __popcll(hw[1]) + __popcll(hw[2]) + __popcll(hw[3]);  // uniform over the workgroup
+        total_hits += nnew;
+        int off = pend;
+        pend += nnew;
+        if (pend == 0 || (pend < 256 && base + 256 < row_end && nnew == 0)) continue;
         unsigned long long hitb = 0ull;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -385,6 +388,9 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
             s_t[pos] = t;
             s_m[pos] = mask;
         }
+        if (pend < 256 && base + 256 < row_end) continue;
+        const int nhit = pend;
+        pend = 0;
         __syncthreads();
 
         // ---- process the hit rows, KB_NCT column tiles (= KB_NCT*RPT rows) per staging round.  The global loads of
