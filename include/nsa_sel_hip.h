@@ -103,6 +103,22 @@ NSA_API int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const 
                      size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Band attention forward: the sliding-window and the compressed branch (next row of the scope table after the selected
+ * branch).  Query row t (absolute position t0 + t) attends the contiguous key interval [max(0, hi - w), hi) with
+ *     hi(t) = (t0 + t + 1 >= a) ? min(S_kv, (t0 + t + 1 - a) / dd + c) : 0 ;
+ *   sliding window (sliding_window_attention, nsa/core/attention_kernels.py:146-178): a = 0, dd = 1, c = 0, w = window;
+ *   compressed (emission schedule num_cmp(t), attention_kernels.py:118-121): a = l, dd = d, c = 1, w = INT_MAX (K/V = K_cmp/V_cmp).
+ * Layouts, strides, scale, lse and the empty-row rule (zeros, lse = -inf) as in nsa_sel_attn_fwd.  Prefill passes t0 = 0 and
+ * all S rows; a decode step passes S = 1 and t0 = position of the new token.
+ *   variant 0 = auto, 1 = generic VALU kernel (any dtype, D <= 256), 2 = MFMA kernel (bf16/f16, Dk = Dv = 64, h <= 16).
+ * ------------------------------------------------------------------------------------- */
+NSA_API size_t nsa_band_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype);
+NSA_API int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int S, int G, int h,
+                      int Dk, int Dv, int S_kv, int64_t k_stride_b, int64_t k_stride_g, int64_t k_stride_s,
+                      int64_t v_stride_b, int64_t v_stride_g, int64_t v_stride_s, int t0, int a, int dd, int c, int w,
+                      int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Eq.9 map in gather (CSC) form.  For selection block j the entries csc_ptr[j]..csc_ptr[j+1]
  * list (cmp row, weight) in ASCENDING cmp row -- the order the reference's CPU scatter_add
  * accumulates in -- so p_slc is bit-identical to the reference given an identical fp32 p_cmp.

@@ -6,6 +6,11 @@ the arithmetic lives in hand-written HIP kernels behind the C ABI include/nsa_se
 (libnsa_sel_hip.so).  There is no CPU or eager fallback: a missing library raises.
 """
 from . import _lib  # noqa: F401
+from .band_attention import (  # noqa: F401
+    band_attention_hip,
+    batched_causal_attention_compressed,
+    sliding_window_attention,
+)
 from .block_index import BlockMeta, build_block_meta, build_block_starts, build_M_csl_csr  # noqa: F401
 from .selection_attention import (  # noqa: F401
     grouped_selection_attention_masked,

@@ -27,6 +27,8 @@ SIGNATURES = {
     "nsa_sel_attn_fwd": (_i, [_vp] * 6 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_sel_attn_bwd_workspace": (_sz, [_i] * 9),
     "nsa_sel_attn_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
+    "nsa_band_attn_fwd_workspace": (_sz, [_i] * 7),
+    "nsa_band_attn_fwd": (_i, [_vp] * 5 + [_i] * 7 + [_i64] * 6 + [_i] * 5 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_block_counts": (_i, [_i] * 4 + [C.POINTER(_i)] * 3),
     "nsa_build_block_meta_host": (_i, [_i] * 4 + [_vp] * 6),
     "nsa_map_pcmp_to_pgrp": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -1,0 +1,352 @@
+// MFMA band attention forward for gfx950 (bf16 / f16, Dk = Dv = 64, h <= 16): the sliding-window and the compressed
+// branch of NSA (reference: sliding_window_attention, nsa/core/attention_kernels.py:146-178; compressed branch with the
+// num_cmp(t) emission schedule, :106-143).  Query row t attends the contiguous key interval [lo(t), hi(t)) defined in
+// sel_attn_params.hpp (BandAttnParams); rows with an empty interval give zeros.
+//
+// Mapping: one wave64 = TPW consecutive tokens of one (b,g) with all their h heads: NT*16 (token, head) "slots" are the
+// columns of NT 16x16x32 MFMA tiles (h = 6, NT = 3: 8 tokens x 6 heads = 48 slots, every column used).  A K/V tile of 32
+// keys is brought into wave-private LDS once (LDS-DMA) and its fragments are reused by all NT column tiles, so the band
+// around TPW tokens costs (w + TPW) key rows per wave instead of w per token.  The product is computed transposed like
+// the selection kernel (S^T = K.Q^T, O^T += V^T.P^T): softmax statistics are per lane (= per slot) and the S^T
+// accumulators feed the PV MFMA without any lane movement.  Tiles that lie inside every slot's interval take the
+// mask-free path with deferred max; only the tiles on the window edge / causal diagonal apply per-slot masks.
+// A 256-thread workgroup = 4 consecutive token groups; all LDS is wave private (no workgroup barrier).
+#include <stdlib.h>
+
+#include "attn_mfma_tiles.hpp"
+
+namespace nsa {
+
+template <typename T, int NT, bool SPLIT>
+__global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
+    using M = MfmaT<T>;
+    using G_ = Geo<64>;
+    using x8 = typename M::x8;
+    using x4 = typename M::x4;
+    constexpr int D = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int tpw = P.tpw, h = P.h;
+    const int ngrp = (P.S + tpw - 1) / tpw;  // token groups per (b,g)
+    const int nbg = P.B * P.G;
+    int bg, grp, sp = 0;
+    if (SPLIT) {
+        const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+        const int64_t gi = wid / P.nsplit;
+        sp = (int)(wid - gi * P.nsplit);
+        bg = (int)(gi / ngrp);
+        grp = (int)(gi - (int64_t)bg * ngrp);
+        if (bg >= nbg) return;
+    } else {
+        const int W = (ngrp + 3) >> 2;  // workgroups per (b,g)
+        int tc;
+        if (P.map_mode == 2) {  // whole (b,g) pairs per XCD (workgroups go round-robin over the 8 XCDs)
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            bg = (idx / W) * 8 + xcd;
+            tc = idx % W;
+        } else {
+            bg = blockIdx.x / W;
+            tc = blockIdx.x % W;
+        }
+        grp = 4 * tc + wave;
+        if (grp >= ngrp || bg >= nbg) return;
+    }
+    const int b = bg / P.G, g = bg - b * P.G;
+    const int tw0 = grp * tpw, ntok = min(tpw, P.S - tw0);
+
+    unsigned char *kl = smem + (size_t)wave * (2 * G_::TILE_BYTES);
+    unsigned char *vl = kl + G_::TILE_BYTES;
+
+    // ---- key interval of the wave and of every slot (hi and lo are non-decreasing in t)
+    const int hi_min = band_hi(P.t0, P.a, P.dd, P.c, P.S_kv, tw0);
+    const int hi_max = band_hi(P.t0, P.a, P.dd, P.c, P.S_kv, tw0 + ntok - 1);
+    const int klo = max(0, hi_min - P.w), lo_max = max(0, hi_max - P.w);
+    const int rho = lane & 15, q = lane >> 4;
+    int hi_s[NT], lo_s[NT];
+    int64_t orow[NT];  // (row * h + head) of the slot, -1 = unused slot
+    x8 qf[NT][2];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int slot = 16 * n + rho, tok = slot / h, head = slot - tok * h;
+        const bool used = tok < ntok;
+        const int t = tw0 + tok;
+        hi_s[n] = used ? band_hi(P.t0, P.a, P.dd, P.c, P.S_kv, t) : 0;
+        lo_s[n] = max(0, hi_s[n] - P.w);
+        orow[n] = used ? ((((int64_t)b * P.S + t) * P.G + g) * h + head) : -1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (used) raw = *(const u32x4 *)((const T *)P.Q + orow[n] * D + 32 * s + 8 * q);
+            qf[n][s] = __builtin_bit_cast(x8, raw);
+        }
+    }
+
+    const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
+    const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
+    const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;
+    auto make_rsrc = [&](const unsigned char *base, int64_t bytes) {
+        const uint64_t a = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + G_::ROWB);
+    const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + G_::ROWB);
+    const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    const int kstep = uniform(G_::RPI * (int)krowb), vstep = uniform(G_::RPI * (int)vrowb);
+    const int ld_row = lane / G_::PIECES, ld_piece = lane % G_::PIECES;
+    uint32_t kdma[G_::NLD], vdma[G_::NLD];
+#pragma unroll
+    for (int i = 0; i < G_::NLD; ++i) {
+        const int r = i * G_::RPI + ld_row;
+        kdma[i] = (uint32_t)(ld_row * krowb + ((ld_piece ^ G_::swz_k(r)) << 4));
+        vdma[i] = (uint32_t)(ld_row * vrowb + (((((ld_piece >> 1) ^ G_::swz_v(r)) << 1) | (ld_piece & 1)) << 4));
+    }
+    uint32_t krd0[2], vrd0[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) krd0[s] = rho * G_::ROWB + (((4 * s + q) ^ G_::swz_k(rho)) << 4);
+    {
+        const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) vrd0[m] = r * G_::ROWB + ((m ^ G_::swz_v(r)) << 5) + 8 * pp;
+    }
+    // a tile of 32 keys starting at tok0 -> wave-private LDS (swizzle applied on the source side); rows past the end of
+    // K/V re-read the last row (they are masked: only boundary tiles reach past hi)
+    auto issue_dma = [&](int tok0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);
+        if (tok0 + 32 <= P.S_kv) {
+#pragma unroll
+            for (int i = 0; i < G_::NLD; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(kl + i * 1024), 16, kdma[i], ks + i * kstep, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(vl + i * 1024), 16, vdma[i], vs + i * vstep, 0, 0);
+            }
+        } else {
+            const int last = P.S_kv - 1 - tok0;
+#pragma unroll
+            for (int i = 0; i < G_::NLD; ++i) {
+                const int r = i * G_::RPI + ld_row;
+                const int rc = min(r, last);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(kl + i * 1024), 16,
+                                                         rc * krowb32 + ((ld_piece ^ G_::swz_k(r)) << 4), ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(vl + i * 1024), 16,
+                                                         rc * vrowb32 + (((((ld_piece >> 1) ^ G_::swz_v(r)) << 1) | (ld_piece & 1)) << 4), vs, 0, 0);
+            }
+        }
+#else
+        (void)tok0;
+#endif
+    };
+
+    f32x4 o[NT][4];
+    float mrun[NT], lrun[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // unused slots carry +inf so that their (zero) scores never trigger the max-raising path
+        mrun[n] = orow[n] >= 0 ? -INFINITY : INFINITY;
+        lrun[n] = 0.f;
+    }
+    const float c2 = P.scale * LOG2E;
+
+    // tiles of this wave (SPLIT: a contiguous share of them)
+    const int ntile_all = hi_max > klo ? (hi_max - klo + 31) >> 5 : 0;
+    int tile = 0, tile_end = ntile_all;
+    if (SPLIT) {
+        tile = (int)(((int64_t)ntile_all * sp) / P.nsplit);
+        tile_end = (int)(((int64_t)ntile_all * (sp + 1)) / P.nsplit);
+    }
+    if (tile < tile_end) issue_dma(klo + 32 * tile);
+
+    for (; tile < tile_end; ++tile) {
+        const int tok0 = klo + 32 * tile;
+        x8 kfr[2][2];
+        x8 va[4];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is a vmcnt event
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kfr[u][s] = *(const x8 *)(kl + krd0[s] + u * 16 * G_::ROWB);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const x4 lo = M::tr(vl + vrd0[m]), hi = M::tr(vl + vrd0[m] + 16 * G_::ROWB);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                va[m][j] = lo[j];
+                va[m][4 + j] = hi[j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffers may be refilled
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + 1 < tile_end) issue_dma(tok0 + 32);
+
+        const bool interior = tok0 >= lo_max && tok0 + 32 <= hi_min;  // every key valid for every slot
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 sacc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                sacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) sacc[u] = M::mma(kfr[u][s], qf[n][s], sacc[u]);
+            }
+            // key of sacc[u][j] = tok0 + 16u + 4q + j
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[4 * u + j] = fmaf(sacc[u][j], c2, -mrun[n]);
+            const float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+            if (!interior || __any(!(tmax <= RESCALE_THR))) {
+                asm volatile("; slow path: masks and/or raise the running max" ::: "memory");
+                float vmax = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = tok0 + 16 * u + 4 * q + j;
+                        const float v = (key >= lo_s[n] && key < hi_s[n]) ? sacc[u][j] * c2 : -INFINITY;
+                        x[4 * u + j] = v;
+                        vmax = fmaxf(vmax, v);
+                    }
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 16, 64));
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+                const float mnew = fmaxf(mrun[n], vmax);
+                const float msub = (mnew == -INFINITY) ? 0.f : mnew;  // nothing valid seen yet: keep x = -inf, p = 0
+                const float alpha = (mnew == mrun[n]) ? 1.f : __builtin_amdgcn_exp2f(mrun[n] - msub);
+                mrun[n] = mnew;
+                lrun[n] *= alpha;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) o[n][m] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] -= msub;
+            }
+            float psum = 0.f;
+            x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pe = __builtin_amdgcn_exp2f(x[j]);
+                psum += pe;
+                pf[j] = Elt<T>::from_f(pe);
+            }
+            lrun[n] += psum;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[n][m] = M::mma(va[m], pf, o[n][m]);
+        }
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float ltot = lrun[n] + __shfl_xor(lrun[n], 16, 64);
+        ltot += __shfl_xor(ltot, 32, 64);
+        if (orow[n] < 0) continue;
+        if (SPLIT) {
+            // partial record [row][sp][head][PART_PAD + D] in the layout of the selection kernel's combine pass
+            const int64_t row = orow[n] / h;
+            const int head = (int)(orow[n] - row * h);
+            float *pr = P.part + ((row * P.nsplit + sp) * (int64_t)h + head) * (D + PART_PAD);
+            if (q == 0) {
+                pr[0] = mrun[n];
+                pr[1] = ltot;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) *(f32x4 *)(pr + PART_PAD + 16 * m + 4 * q) = o[n][m];
+        } else {
+            const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+            T *Or = (T *)P.O + orow[n] * D;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = Elt<T>::from_f(o[n][m][j] * inv);
+                *(x4 *)(Or + 16 * m + 4 * q) = ov;
+            }
+            if (P.lse && q == 0) P.lse[orow[n]] = ltot > 0.f ? (mrun[n] + __builtin_amdgcn_logf(ltot)) * LN2 : -INFINITY;
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv) {
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
+}
+
+// NT = 3 column tiles per wave (48 / h tokens) once there are enough tokens to fill the chip, NT = 1 (16 / h tokens)
+// below that; with very few token groups (decode) the key interval is also split over several waves.
+static void band_plan(int B, int S, int G, int h, int *nt, int *tpw, int *nsplit) {
+    const int tpw3 = 48 / h, tpw1 = 16 / h;
+    const int64_t grp3 = (int64_t)B * G * ((S + tpw3 - 1) / tpw3);
+    if (grp3 >= 2048) {
+        *nt = 3, *tpw = tpw3, *nsplit = 1;
+        return;
+    }
+    *nt = 1, *tpw = tpw1;
+    const int64_t grp1 = (int64_t)B * G * ((S + tpw1 - 1) / tpw1);
+    int ns = 1;
+    if (grp1 < 1024) {
+        ns = (int)((2048 + grp1 - 1) / grp1);
+        if (ns > 16) ns = 16;
+    }
+    *nsplit = ns;
+}
+
+size_t band_attn_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int *nsplit_out) {
+    int nt = 1, tpw = 1, ns = 1;
+    if (band_attn_mfma_supported(dtype, h, Dk, Dv)) band_plan(B, S, G, h, &nt, &tpw, &ns);
+    if (nsplit_out) *nsplit_out = ns;
+    return ns > 1 ? (size_t)B * S * G * ns * h * (Dv + PART_PAD) * sizeof(float) : 0;
+}
+
+template <typename T>
+static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
+    BandAttnParams P = P0;
+    int nt = 1, ns = 1;
+    band_plan(P.B, P.S, P.G, P.h, &nt, &P.tpw, &ns);
+    const bool split = ns > 1 && P.part != nullptr && P.nsplit == ns;
+    if (!split) P.nsplit = 1;
+    const int64_t nbg = (int64_t)P.B * P.G;
+    const int ngrp = (P.S + P.tpw - 1) / P.tpw;
+    const size_t lds = 4 * (size_t)(2 * Geo<64>::TILE_BYTES);
+    if (split) {
+        const int64_t waves = nbg * ngrp * P.nsplit;
+        hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st, P);
+        NSA_LAUNCH_CHECK("band_attn_fwd(split)");
+        SelAttnParams C{};
+        C.O = P.O;
+        C.lse = P.lse;
+        C.R = nbg * P.S;
+        C.h = P.h;
+        C.part = P.part;
+        C.nsplit = P.nsplit;
+        hipLaunchKernelGGL((sel_attn_combine_kernel<T, 64>), dim3((unsigned)((C.R * C.h + 3) / 4)), dim3(256), 0, st, C);
+        NSA_LAUNCH_CHECK("band_attn_combine");
+        return NSA_OK;
+    }
+    const int64_t W = (ngrp + 3) / 4;
+    P.map_mode = (nbg % 8 == 0) ? 2 : 1;
+    NSA_CHECK_ARG(nbg * W < ((int64_t)1 << 31), "band_attn: too many workgroups for one launch");
+    const unsigned grid = (unsigned)(nbg * W);
+    if (nt == 3) hipLaunchKernelGGL((band_attn_fwd_kernel<T, 3, false>), dim3(grid), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, false>), dim3(grid), dim3(256), lds, st, P);
+    NSA_LAUNCH_CHECK("band_attn_fwd");
+    return NSA_OK;
+}
+
+int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st) {
+    NSA_CHECK_ARG(band_attn_mfma_supported(dtype, P.h, P.Dk, P.Dv), "band MFMA kernel: unsupported dtype/h/Dk/Dv = %d/%d/%d/%d", dtype, P.h,
+                  P.Dk, P.Dv);
+    NSA_CHECK_ARG(P.kss % 8 == 0 && P.vss % 8 == 0 && P.ksb % 8 == 0 && P.vsb % 8 == 0 && P.ksg % 8 == 0 && P.vsg % 8 == 0,
+                  "band MFMA kernel: K/V strides must be multiples of 8 elements (16 B)");
+    NSA_CHECK_ARG(((uintptr_t)P.Q % 16 == 0) && ((uintptr_t)P.K % 16 == 0) && ((uintptr_t)P.V % 16 == 0) && ((uintptr_t)P.O % 8 == 0),
+                  "band MFMA kernel: Q/K/V must be 16-byte aligned");
+    NSA_CHECK_ARG((int64_t)P.S_kv * P.kss * 2 < ((int64_t)1 << 31) && (int64_t)P.S_kv * P.vss * 2 < ((int64_t)1 << 31),
+                  "band MFMA kernel: one (b,g) K/V slab must be smaller than 2 GiB (buffer addressing)");
+    if (dtype == NSA_DT_BF16) return launch_band_t<__bf16>(P, st);
+    return launch_band_t<_Float16>(P, st);
+}
+
+}  // namespace nsa

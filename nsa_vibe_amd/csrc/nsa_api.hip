@@ -174,6 +174,47 @@ int nsa_sel_attn_bwd(const void *Q, const void *K, const void *V, const int32_t 
     return launch_sel_attn_bwd_generic(P, dtype, st);
 }
 
+// ------------------------------------------------------------------------------ band attention
+size_t nsa_band_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype) {
+    return band_attn_workspace(B, S, G, h, Dk, Dv, dtype, nullptr);
+}
+
+int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk,
+                      int Dv, int S_kv, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int t0,
+                      int a, int dd, int c, int w, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "band_attn_fwd: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0, "band_attn_fwd: negative size");
+    NSA_CHECK_ARG(t0 >= 0 && dd >= 1 && w >= 0, "band_attn_fwd: need t0 >= 0, dd >= 1, w >= 0");
+    NSA_CHECK_ARG(variant >= 0 && variant <= 2, "band_attn_fwd: unknown variant %d", variant);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    // S_kv == 0 or w == 0: every interval is empty; the generic kernel writes the zeros / -inf rows
+    NSA_CHECK_ARG(Q && O && ((K && V) || S_kv == 0), "band_attn_fwd: null pointer");
+    BandAttnParams P{};
+    P.Q = Q; P.K = K; P.V = V; P.O = O; P.lse = lse;
+    P.B = B; P.S = S; P.G = G; P.h = h; P.Dk = Dk; P.Dv = Dv; P.S_kv = S_kv;
+    P.ksb = ksb; P.ksg = ksg; P.kss = kss; P.vsb = vsb; P.vsg = vsg; P.vss = vss;
+    P.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    P.t0 = t0; P.a = a; P.dd = dd; P.c = c; P.w = w;
+    const bool fast_ok = S_kv > 0 && w > 0 && band_attn_mfma_supported(dtype, h, Dk, Dv) && kss % 8 == 0 && vss % 8 == 0 && ksb % 8 == 0 &&
+                         vsb % 8 == 0 && ksg % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) &&
+                         ((uintptr_t)V % 16 == 0) && ((uintptr_t)O % 8 == 0) && (int64_t)S_kv * kss * 2 < ((int64_t)1 << 31) &&
+                         (int64_t)S_kv * vss * 2 < ((int64_t)1 << 31);
+    if (variant == 2) NSA_CHECK_ARG(fast_ok, "band_attn_fwd: MFMA variant requested but shape/dtype/alignment unsupported");
+    if (fast_ok && variant != 1) {
+        int ns = 1;
+        const size_t need = band_attn_workspace(B, S, G, h, Dk, Dv, dtype, &ns);
+        if (ns > 1 && workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0)) {
+            P.part = (float *)workspace;
+            P.nsplit = ns;
+        }
+        return launch_band_attn_fwd_mfma(P, dtype, st);
+    }
+    return launch_band_attn_fwd_generic(P, dtype, st);
+}
+
 // ------------------------------------------------------------------------------ block meta (host)
 int nsa_block_counts(int seq_len, int l, int d, int l_sel, int *S_cmp, int *S_sel, int *nnz) {
     NSA_CHECK_ARG(l > 0 && d > 0 && l_sel > 0, "Block parameters must be positive");

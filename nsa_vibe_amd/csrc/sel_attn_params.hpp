@@ -36,6 +36,35 @@ struct SelAttnBwdParams {
     float scale;
 };
 
+// Band attention (sliding-window and compressed branches): query row t (position t0 + t) attends keys [max(0, hi - w), hi),
+//   hi(t) = (t0 + t + 1 >= a) ? min(S_kv, (t0 + t + 1 - a) / dd + c) : 0.
+// sliding window: a = 0, dd = 1, c = 0 (hi = t + 1), w = window; compressed: a = l, dd = d, c = 1, w = "infinite".
+struct BandAttnParams {
+    const void *Q;  // [B,S,G,h,D]
+    const void *K;  // [B,G,S_kv,D] with element strides ksb/ksg/kss
+    const void *V;
+    void *O;        // [B,S,G,h,D]
+    float *lse;     // [B,S,G,h] or null
+    int B, S, G, h, Dk, Dv, S_kv;
+    int64_t ksb, ksg, kss, vsb, vsg, vss;
+    float scale;
+    int t0, a, dd, c, w;
+    float *part;  // split-KV partial records (few rows) or null
+    int nsplit;
+    int map_mode;  // 0 linear, 1 workgroup = 4 token groups of one (b,g), 2 = 1 + XCD-aware order
+    int tpw;       // tokens per wave
+};
+__host__ __device__ inline int band_hi(int t0, int a, int dd, int c, int S_kv, int t) {
+    const int e = t0 + t + 1 - a;
+    if (e < 0) return 0;
+    const int hi = e / dd + c;
+    return hi < S_kv ? hi : S_kv;
+}
+bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
+size_t band_attn_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int *nsplit_out);
+int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st);
+int launch_band_attn_fwd_generic(const BandAttnParams &P, int dtype, hipStream_t st);
+
 int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);
 int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_t st);
 // returns NSA_ERR_INVALID (without setting an error) when the shape is not covered

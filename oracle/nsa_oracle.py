@@ -206,6 +206,47 @@ def sel_attention_masked_bwd(Q, K, V, ranges, dO, scale: float | None = None):
     return dQ, dK, dV
 
 
+def band_ranges(S: int, S_kv: int, t0: int = 0, a: int = 0, dd: int = 1, c: int = 0, w: int = 2 ** 30) -> np.ndarray:
+    """Key interval [lo, hi) of query row t (position t0 + t) for the sliding / compressed branches, [S,2] int32:
+    hi = 0 if t0+t+1 < a else min(S_kv, (t0+t+1-a)//dd + c); lo = max(0, hi - w).
+    Sliding window (nsa/core/attention_kernels.py:159-161: allowed = col <= row & col >= row-(w-1)): a=0, dd=1, c=0.
+    Compressed (attention_kernels.py:118-121: num_cmp = 0 if t+1 < l else (t+1-l)//d + 1, clamped to S_cmp): a=l, dd=d, c=1."""
+    e = np.arange(S, dtype=np.int64) + (t0 + 1 - a)
+    hi = np.where(e < 0, 0, np.maximum(e, 0) // dd + c)
+    hi = np.minimum(hi, S_kv)
+    lo = np.maximum(hi - w, 0)
+    return np.stack((lo, hi), axis=-1).astype(np.int32)
+
+
+def band_attention(Q, K, V, *, t0: int = 0, a: int = 0, dd: int = 1, c: int = 0, w: int = 2 ** 30, scale=None,
+                   return_lse: bool = False):
+    """Softmax attention of row t over its key interval (band_ranges); rows with an empty interval give zeros.
+    Restated through sel_attention_masked with one range per row (the masked SDPA of attention_kernels.py:163-177
+    is the same math as :705-772 with this mask)."""
+    Q = _f32(Q)
+    B, S, G = Q.shape[:3]
+    rg = np.broadcast_to(band_ranges(S, np.asarray(K).shape[2], t0, a, dd, c, w).reshape(1, S, 1, 1, 2), (B, S, G, 1, 2))
+    return sel_attention_masked(Q, K, V, np.ascontiguousarray(rg), scale, return_lse)
+
+
+def band_attention_bwd(Q, K, V, dO, *, t0: int = 0, a: int = 0, dd: int = 1, c: int = 0, w: int = 2 ** 30, scale=None):
+    Q = _f32(Q)
+    B, S, G = Q.shape[:3]
+    rg = np.broadcast_to(band_ranges(S, np.asarray(K).shape[2], t0, a, dd, c, w).reshape(1, S, 1, 1, 2), (B, S, G, 1, 2))
+    return sel_attention_masked_bwd(Q, K, V, np.ascontiguousarray(rg), dO, scale)
+
+
+def sliding_window_attention(Q, K, V, w: int, *, t0: int = 0, scale=None):
+    """nsa/core/attention_kernels.py:146-178 (w <= 0 or no keys -> zeros, :153-154)."""
+    return band_attention(Q, K, V, t0=t0, a=0, dd=1, c=0, w=max(int(w), 0), scale=scale)
+
+
+def batched_causal_attention_compressed(Q, K_cmp, V_cmp, l: int, d: int, *, t0: int = 0, scale=None):
+    """Compressed branch with the mask of attention_kernels.py:118-123 and a true softmax over the allowed tokens
+    (the reference's per-token call at :139-141 degenerates to key 0; see nsa_vibe_amd/band_attention.py)."""
+    return band_attention(Q, K_cmp, V_cmp, t0=t0, a=int(l), dd=int(d), c=1, scale=scale)
+
+
 def normalise_ranges(r: np.ndarray) -> list:
     """Drop e<=s entries (SURVEY 7 hard part (c)); returns nested lists of (s,e) per row."""
     r = np.asarray(r)

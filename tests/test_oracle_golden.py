@@ -181,3 +181,24 @@ def test_attention_bwd_oracle_matches_finite_difference(orc):
             args2 = [a2 if x is arr else x for x in (Q, K, V)]
             fd = (loss(*args1) - loss(*args2)) / (2 * eps)
             assert abs(fd - grad[idx]) < 5e-3 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_g13_sliding_window(orc, name):
+    """oracle restatement == reference sliding_window_attention (attention_kernels.py:146-178)"""
+    g = load_golden("g13_win_" + name)
+    O = orc.sliding_window_attention(g["Q"], g["K"], g["V"], int(g["w"]))
+    assert np.abs(O - g["O"]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_g13_compressed(orc, name):
+    """oracle == SDPA under the reference's num_cmp mask (attention_kernels.py:118-123); band_ranges == num_cmp"""
+    g = load_golden("g13_cmp_" + name)
+    S, S_cmp = g["Q"].shape[1], g["K"].shape[2]
+    rg = orc.band_ranges(S, S_cmp, 0, int(g["l"]), int(g["d"]), 1)
+    assert np.array_equal(rg[:, 1], g["num_cmp"]) and not rg[:, 0].any()
+    O = orc.batched_causal_attention_compressed(g["Q"], g["K"], g["V"], int(g["l"]), int(g["d"]))
+    assert np.abs(O - g["O"]).max() <= 2e-5
+    if name == "b":
+        assert not O.any()

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Full NSAAttention layer (cmp + sel + win + gate) on one GPU: prefill ms and decode tok/s at the m7c shape (bf16).
+
+    python tools/bench_module.py [S] [B] [decode_steps]
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nsa_vibe_amd as nv  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+torch.manual_seed(0)
+dev = torch.device("cuda")
+m = nv.NSAAttention(768, 12, 2, 64, 64, 32, 16, 64, 16, 512, selector="batched").to(dev).to(torch.bfloat16).eval()
+x = torch.randn(B, S, 768, device=dev, dtype=torch.bfloat16)
+with torch.no_grad():
+    for it in range(3):
+        kv = m.new_kv(B, S + steps + 8, dev, torch.bfloat16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y, kv = m(x, kv, prefill=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    print(f"prefill S={S} B={B}: {1e3 * (t1 - t0):.3f} ms  ({B * S / (t1 - t0) / 1e6:.2f} M tok/s)")
+    xt = torch.randn(B, 1, 768, device=dev, dtype=torch.bfloat16)
+    for _ in range(8):
+        y, kv = m(xt, kv, prefill=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps - 8):
+        y, kv = m(xt, kv, prefill=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (steps - 8)
+    print(f"decode ctx={S} B={B}: {1e6 * dt:.1f} us/step  ({B / dt:.0f} tok/s per layer)")
