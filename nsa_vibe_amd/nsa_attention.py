@@ -8,10 +8,10 @@ What runs where:
   * selected branch (the hot path): scores -> top-n ranges -> selection attention on the HIP kernels
     (selection_scorer.py / selection_attention.py); no Python loop over t, no host sync, no O(S^2) mask.
     Semantics = the reference's masked route (NSA_FORCE_SEL_MASK=1, the production setting).
-  * projections, RoPE, avg-pool phi, gate MLP, compressed and sliding branches: plain PyTorch-ROCm ops (out of
-    scope of the hot path).  The compressed / sliding branches use true causal softmax
-    attention; the reference's default SDPA routes for them degenerate to "first key only" for single-query calls
-    (is_causal=True with L_q=1) -- a quirk that is deliberately not reproduced.
+  * compressed and sliding branches: the HIP band-attention kernel (band_attention.py).  They use true causal
+    softmax attention; the reference's default SDPA routes for them degenerate to "first key only" for
+    single-query calls (is_causal=True with L_q=1) -- a quirk that is deliberately not reproduced.
+  * projections, RoPE, avg-pool phi, gate MLP: plain PyTorch-ROCm ops.
 Selector semantics: `selector="sequential"` (reference default prefill, :1521-1723, and decode) or `"batched"`
 (NSA_PREFILL_BATCHED=1, :978-1448).
 """
@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .band_attention import batched_causal_attention_compressed, sliding_window_attention
 from .kv_cache import NSA_KV
 from .selection_attention import selection_attention_hip, selection_decode_step
 from .selection_scorer import select_topn_ranges_batched, select_topn_ranges_rows, selection_scores
@@ -70,23 +71,6 @@ class GateMLP(nn.Module):
         peaked = (top2[..., 0] - top2[..., 1]) > 50.0  # hard one-hot when extremely peaked (reference :70-81), sync free
         one_hot = F.one_hot(torch.argmax(g, dim=-1), 3).to(p.dtype)
         return torch.where(peaked.unsqueeze(-1), one_hot, p)
-
-
-def _masked_sdpa(Q, K, V, allowed):
-    """Q [B,Sq,G,h,D], K/V [B,G,Skv,D], allowed [Sq,Skv] bool -> [B,Sq,G,h,Dv]; rows without any key give zeros."""
-    B, Sq, G, h, D = Q.shape
-    if K.shape[2] == 0:
-        return Q.new_zeros((B, Sq, G, h, V.shape[-1]))
-    q = Q.permute(0, 2, 3, 1, 4).reshape(B, G * h, Sq, D)
-    k = K.unsqueeze(2).expand(-1, -1, h, -1, -1).reshape(B, G * h, K.shape[2], D)
-    v = V.unsqueeze(2).expand(-1, -1, h, -1, -1).reshape(B, G * h, V.shape[2], V.shape[-1])
-    any_key = allowed.any(dim=-1)
-    safe = allowed.clone()
-    safe[~any_key, 0] = True
-    mask = torch.zeros(safe.shape, dtype=Q.dtype, device=Q.device).masked_fill(~safe, float("-inf"))
-    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-    o = o * any_key.view(1, 1, Sq, 1).to(o.dtype)
-    return o.reshape(B, G, h, Sq, -1).permute(0, 3, 1, 2, 4)
 
 
 class NSAAttention(nn.Module):
@@ -202,17 +186,9 @@ class NSAAttention(nn.Module):
             ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
         self._last_ranges = ranges
         O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
-        # ---- compressed + sliding branches (torch, query-chunked masks)
-        O_cmp, O_win = torch.empty_like(O_sel), torch.empty_like(O_sel)
-        n_cmp_all = kv.n_cmp
-        for s0 in range(0, S, self.query_chunk):
-            s1 = min(S, s0 + self.query_chunk)
-            t = torch.arange(s0, s1, device=x.device).view(-1, 1)
-            num_cmp = torch.where(t + 1 < self.l, 0, (t + 1 - self.l) // self.d + 1).clamp(max=n_cmp_all)
-            O_cmp[:, s0:s1] = _masked_sdpa(Q[:, s0:s1], kv.K_cmp, kv.V_cmp, torch.arange(n_cmp_all, device=x.device).view(1, -1) < num_cmp)
-            k0 = max(0, s0 - self.w + 1)
-            col = torch.arange(k0, s1, device=x.device).view(1, -1)
-            O_win[:, s0:s1] = _masked_sdpa(Q[:, s0:s1], kv._K_win[:, :, k0:s1], kv._V_win[:, :, k0:s1], (col <= t) & (col > t - self.w))
+        # ---- compressed + sliding branches (HIP band kernel)
+        O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, scale=scale)
+        O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S], kv._V_win[:, :, :S], self.w, scale=scale)
         return self._combine(Q, O_cmp, O_sel, O_win), kv
 
     def _decode(self, x: torch.Tensor, kv: NSA_KV):
@@ -237,7 +213,7 @@ class NSAAttention(nn.Module):
         Qc = Q.contiguous()
         O_sel, ranges = selection_decode_step(Qc, kv.K_cmp, kv.K_sel, kv.V_sel, kv.meta, self.n_sel, t, scale=scale)
         self._last_ranges = ranges
-        ones = lambda n: torch.ones((1, n), dtype=torch.bool, device=x.device)  # noqa: E731
-        O_win = _masked_sdpa(Q, kv.K_win, kv.V_win, ones(kv.K_win.shape[2]))
-        O_cmp = _masked_sdpa(Q, kv.K_cmp, kv.V_cmp, ones(kv.n_cmp)) if kv.n_cmp > 0 else torch.zeros_like(O_sel)
+        # the query sits at position t: window = the last w cached tokens, compressed = every token emitted so far
+        O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S_raw], kv._V_win[:, :, :S_raw], self.w, t0=t, scale=scale)
+        O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, t0=t, scale=scale)
         return self._combine(Q, O_cmp, O_sel, O_win), kv
