@@ -119,6 +119,51 @@ NSA_API int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void 
                       int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Layer-level entry points: NSAAttention around the three branches (nsa/core/nsa_attention.py).  Plain-C descriptors:
+ *   nsa_layer_desc  geometry + weights of one NSAAttention module (state-dict tensors, row-major [out,in] like nn.Linear;
+ *                   W_qkv is the row-wise concatenation W_Q | W_K_sel | W_V_sel | W_K_win | W_V_win | W_K_cmp | W_V_cmp)
+ *   nsa_kv_desc     the preallocated NSA_KV buffers (nsa/cache/kv_cache.py:8-26), each [B,G,S_max,D] contiguous,
+ *                   K_cmp/V_cmp [B,G,n_cmp_max,D]
+ * All tensors of one call share `dtype`.
+ * ------------------------------------------------------------------------------------- */
+typedef struct nsa_layer_desc {
+    int dim, G, h, Dk, Dv, l, d, l_sel, n_sel, w, gate_hidden, dtype;
+    float rope_base, rope_scale, gate_tau;
+    const void *W_qkv;   /* [G*h*Dk + 3*G*Dk + 3*G*Dv, dim] */
+    const void *W_out;   /* [dim, G*h*Dv] */
+    const void *gate_w1; /* [gate_hidden, Dk] */
+    const void *gate_b1; /* [gate_hidden] */
+    const void *gate_w2; /* [3, gate_hidden] */
+    const void *gate_b2; /* [3] */
+} nsa_layer_desc;
+
+typedef struct nsa_kv_desc {
+    void *K_sel, *V_sel, *K_win, *V_win, *K_raw, *V_raw;
+    void *K_cmp, *V_cmp;
+    int B, S_max, n_cmp_max;
+} nsa_kv_desc;
+
+/* out[M,N] = A[M,K] . W[N,K]^T for few rows (decode projections). */
+NSA_API int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, void *stream);
+/* RoPE (Q over the flattened head axis, K_sel/K_win per group; nsa_attention.py:552-572, 1002-1024) on a fused projection
+ * proj [B,S,NQ+3GDk+3GDv] and append of the S tokens at cache position t0: Q_out [B,S,G,h,Dk]. */
+NSA_API int nsa_rope_cache_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, void *Q_out, int S, int t0,
+                          void *stream);
+/* Emit compressed tokens j0 <= j < j1: K_cmp[j] = mean_{i<l} RoPE(K_raw[j d + i]), V_cmp[j] = mean V_raw (compress_pool.py:9-38). */
+NSA_API int nsa_cmp_pool_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, int j0, int j1, void *stream);
+/* Gate MLP + combine (nsa_attention.py:32-82, 85-124): O_out = sum_i gate_i O_i; gates_out [R,3] fp32 nullable; R = B*S*G rows. */
+NSA_API int nsa_gate_combine(const nsa_layer_desc *L, const void *Q, const void *O_cmp, const void *O_sel, const void *O_win,
+                     void *O_out, float *gates_out, int64_t R, void *stream);
+/* One decode step of the whole layer in one call (nsa_attention.py:509-830, decode branch): x [B,dim] is the new token at
+ * position t (= tokens already cached); appends it to the caches, emits a compressed token when due, runs the three branches,
+ * the gate and the output projection -> y [B,dim].  csc_* / S_sel: the Eq.9 map of the block metadata covering t
+ * (nsa_build_block_meta_host).  ranges_out [B,G,n_sel,2] int32 and gates_out [B,G,3] fp32 are nullable monitors. */
+NSA_API size_t nsa_layer_decode_step_workspace(const nsa_layer_desc *L, int B, int S_max);
+NSA_API int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *x, void *y, int t,
+                          const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel,
+                          int32_t *ranges_out, float *gates_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Eq.9 map in gather (CSC) form.  For selection block j the entries csc_ptr[j]..csc_ptr[j+1]
  * list (cmp row, weight) in ASCENDING cmp row -- the order the reference's CPU scatter_add
  * accumulates in -- so p_slc is bit-identical to the reference given an identical fp32 p_cmp.

@@ -18,6 +18,23 @@ NSA_SEL_SEQUENTIAL, NSA_SEL_BATCHED = 0, 1
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
+
+
+class NsaLayerDesc(C.Structure):
+    """struct nsa_layer_desc (include/nsa_sel_hip.h)"""
+    _fields_ = [(n, _i) for n in ("dim", "G", "h", "Dk", "Dv", "l", "d", "l_sel", "n_sel", "w", "gate_hidden", "dtype")] + \
+               [(n, _f) for n in ("rope_base", "rope_scale", "gate_tau")] + \
+               [(n, _vp) for n in ("W_qkv", "W_out", "gate_w1", "gate_b1", "gate_w2", "gate_b2")]
+
+
+class NsaKvDesc(C.Structure):
+    """struct nsa_kv_desc (include/nsa_sel_hip.h)"""
+    _fields_ = [(n, _vp) for n in ("K_sel", "V_sel", "K_win", "V_win", "K_raw", "V_raw", "K_cmp", "V_cmp")] + \
+               [(n, _i) for n in ("B", "S_max", "n_cmp_max")]
+
+
+_pl, _pk = C.POINTER(NsaLayerDesc), C.POINTER(NsaKvDesc)
+
 # name -> (restype, argtypes); mirrors include/nsa_sel_hip.h one to one
 SIGNATURES = {
     "nsa_hip_abi_version": (_i, []),
@@ -29,6 +46,12 @@ SIGNATURES = {
     "nsa_sel_attn_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_band_attn_fwd_workspace": (_sz, [_i] * 7),
     "nsa_band_attn_fwd": (_i, [_vp] * 5 + [_i] * 7 + [_i64] * 6 + [_i] * 5 + [_i, _f, _i, _vp, _sz, _vp]),
+    "nsa_linear_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nsa_rope_cache_append": (_i, [_pl, _pk, _vp, _vp, _i, _i, _vp]),
+    "nsa_cmp_pool_append": (_i, [_pl, _pk, _i, _i, _vp]),
+    "nsa_gate_combine": (_i, [_pl, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "nsa_layer_decode_step_workspace": (_sz, [_pl, _i, _i]),
+    "nsa_layer_decode_step": (_i, [_pl, _pk, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nsa_block_counts": (_i, [_i] * 4 + [C.POINTER(_i)] * 3),
     "nsa_build_block_meta_host": (_i, [_i] * 4 + [_vp] * 6),
     "nsa_map_pcmp_to_pgrp": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

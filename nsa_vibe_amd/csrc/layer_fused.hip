@@ -1,0 +1,237 @@
+// Layer-level pieces of NSAAttention around the three attention branches (the "next" rows of the scope table):
+//   * small-M linear (decode projections): out[M,N] = A[M,K] . W[N,K]^T
+//   * RoPE + KV-cache append of a fused QKV projection (reference: nsa_attention.py:552-572 decode, :1002-1024 prefill;
+//     rope.py:16-51)
+//   * compressed-token emission phi = mean over l raw tokens of RoPE'd K and raw V (compress_pool.py:9-38,
+//     nsa_attention.py:588-604)
+//   * gate MLP + 3-branch combine (nsa_attention.py:32-82, 85-124)
+// Arithmetic follows the PyTorch operator chain the reference runs, including where it rounds to the activation dtype
+// (rnd() below), so a bf16 module gives the same numbers whether these kernels or the eager ops are used.
+#include "nsa_common.hpp"
+#include "layer_fused.hpp"
+
+namespace nsa {
+
+template <typename T>
+__device__ __forceinline__ float rnd(float x) {
+    return Elt<T>::to_f(Elt<T>::from_f(x));
+}
+
+// rotate the pair (x0, x1) of pair index i (of D/2) at position pos
+template <typename T>
+__device__ __forceinline__ void rope_pair(float x0, float x1, int i, int D, float pos, float base, float inv_scale, float &r0, float &r1) {
+    const float e = (-2.0f * (float)i) / (float)D;
+    const float inv_freq = powf(base, e);
+    const float ang = (pos * inv_scale) * inv_freq;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    sn = rnd<T>(sn);
+    cs = rnd<T>(cs);
+    r0 = rnd<T>(rnd<T>(x0 * cs) - rnd<T>(x1 * sn));
+    r1 = rnd<T>(rnd<T>(x0 * sn) + rnd<T>(x1 * cs));
+}
+
+// ------------------------------------------------------------------------------------------ small-M linear
+template <typename T>
+__global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M,
+                                                           int N, int K) {
+    const int lane = lane_id();
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const T *w = W + (int64_t)n * K;
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int mm = min(8, M - m0);
+        for (int k = lane * 8; k < K; k += 512) {
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = (k + j < K) ? Elt<T>::to_f(w[k + j]) : 0.f;
+            for (int r = 0; r < mm; ++r) {
+                const T *a = A + (int64_t)(m0 + r) * K + k;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k + j < K) acc[r] = fmaf(wv[j], Elt<T>::to_f(a[j]), acc[r]);
+            }
+        }
+        for (int r = 0; r < mm; ++r) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0) out[(int64_t)(m0 + r) * N + n] = Elt<T>::from_f(s);
+        }
+    }
+}
+
+template <typename T>
+static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(linear_small_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K);
+    NSA_LAUNCH_CHECK("linear_small");
+    return NSA_OK;
+}
+int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
+    if (dtype == NSA_DT_F32) return linear_small_t<float>(A, W, out, M, N, K, st);
+    if (dtype == NSA_DT_BF16) return linear_small_t<__bf16>(A, W, out, M, N, K, st);
+    return linear_small_t<_Float16>(A, W, out, M, N, K, st);
+}
+
+// ------------------------------------------------------------------------------------------ RoPE + cache append
+template <typename T>
+__global__ __launch_bounds__(256) void rope_cache_append_kernel(RopeAppendParams P) {
+    const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
+    const int NT = NQ + 3 * GK + 3 * GV;
+    const int64_t npair = (int64_t)P.B * P.S * (NT / 2);
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < npair; it += (int64_t)gridDim.x * 256) {
+        const int64_t row = it / (NT / 2);
+        const int col = 2 * (int)(it - row * (NT / 2));
+        const int b = (int)(row / P.S), s = (int)(row - (int64_t)b * P.S);
+        const float pos = (float)(P.t0 + s);
+        const T *src = (const T *)P.proj + row * NT + col;
+        float x0 = Elt<T>::to_f(src[0]), x1 = Elt<T>::to_f(src[1]);
+        if (col < NQ) {  // Q: rotated over the flattened [n_heads * d_k] axis (reference :552-560, :1002-1009)
+            rope_pair<T>(x0, x1, col >> 1, NQ, pos, P.rope_base, P.inv_scale, x0, x1);
+            T *dst = (T *)P.Q_out + row * NQ + col;
+            dst[0] = Elt<T>::from_f(x0);
+            dst[1] = Elt<T>::from_f(x1);
+            continue;
+        }
+        // segments after Q: K_sel | V_sel | K_win | V_win | K_raw | V_raw   (K segments G*Dk wide, V segments G*Dv)
+        int c = col - NQ;
+        const int pairw = GK + GV;
+        const int sp = c / pairw;  // 0 sel, 1 win, 2 raw
+        c -= sp * pairw;
+        const bool isv = c >= GK;
+        if (isv) c -= GK;
+        const int D = isv ? P.Dv : P.Dk;
+        const int g = c / D, dc = c - g * D;
+        if (!isv && sp < 2) rope_pair<T>(x0, x1, dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, x0, x1);  // K_sel, K_win per group
+        T *cache = (T *)P.cache[2 * sp + (isv ? 1 : 0)];
+        T *dst = cache + (((int64_t)b * P.G + g) * P.S_max + (P.t0 + s)) * D + dc;
+        dst[0] = Elt<T>::from_f(x0);
+        dst[1] = Elt<T>::from_f(x1);
+    }
+}
+
+int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st) {
+    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    const int64_t npair = (int64_t)P.B * P.S * (NT / 2);
+    if (npair == 0) return NSA_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((npair + 255) / 256, 65536);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rope_cache_append_kernel<float>, dim3(grid), dim3(256), 0, st, P);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rope_cache_append_kernel<__bf16>, dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(rope_cache_append_kernel<_Float16>, dim3(grid), dim3(256), 0, st, P);
+    NSA_LAUNCH_CHECK("rope_cache_append");
+    return NSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ compressed-token emission
+// one 64-thread block per (b, g, j): K_cmp[j] = mean_i rope(K_raw[j d + i], pos = j d + i), V_cmp[j] = mean_i V_raw[j d + i]
+template <typename T>
+__global__ __launch_bounds__(64) void cmp_pool_kernel(CmpPoolParams P) {
+    const int nj = P.j1 - P.j0;
+    const int j = P.j0 + (int)(blockIdx.x % nj);
+    const int bg = (int)(blockIdx.x / nj);
+    const T *Kr = (const T *)P.K_raw + (int64_t)bg * P.S_max * P.Dk;
+    const T *Vr = (const T *)P.V_raw + (int64_t)bg * P.S_max * P.Dv;
+    T *Kc = (T *)P.K_cmp + ((int64_t)bg * P.n_cmp_max + j) * P.Dk;
+    T *Vc = (T *)P.V_cmp + ((int64_t)bg * P.n_cmp_max + j) * P.Dv;
+    const int r0 = j * P.d;
+    for (int p = threadIdx.x; p < P.Dk / 2; p += 64) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < P.l; ++i) {
+            const T *src = Kr + (int64_t)(r0 + i) * P.Dk + 2 * p;
+            float x0, x1;
+            rope_pair<T>(Elt<T>::to_f(src[0]), Elt<T>::to_f(src[1]), p, P.Dk, (float)(r0 + i), P.rope_base, P.inv_scale, x0, x1);
+            a0 += x0;
+            a1 += x1;
+        }
+        Kc[2 * p] = Elt<T>::from_f(a0 / (float)P.l);
+        Kc[2 * p + 1] = Elt<T>::from_f(a1 / (float)P.l);
+    }
+    for (int c = threadIdx.x; c < P.Dv; c += 64) {
+        float a = 0.f;
+        for (int i = 0; i < P.l; ++i) a += Elt<T>::to_f(Vr[(int64_t)(r0 + i) * P.Dv + c]);
+        Vc[c] = Elt<T>::from_f(a / (float)P.l);
+    }
+}
+
+int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st) {
+    const int64_t nblk = (int64_t)P.nbg * (P.j1 - P.j0);
+    if (nblk <= 0) return NSA_OK;
+    NSA_CHECK_ARG(nblk < ((int64_t)1 << 31), "cmp_pool: too many blocks");
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(cmp_pool_kernel<float>, dim3((unsigned)nblk), dim3(64), 0, st, P);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(cmp_pool_kernel<__bf16>, dim3((unsigned)nblk), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL(cmp_pool_kernel<_Float16>, dim3((unsigned)nblk), dim3(64), 0, st, P);
+    NSA_LAUNCH_CHECK("cmp_pool");
+    return NSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ gate MLP + combine
+// one wave per (b, s, g) row: q_pooled = mean_h Q -> fc1 -> silu -> fc2 -> / tau -> softmax (one-hot when the top two
+// logits are more than 50 apart, nsa_attention.py:70-81) -> O = g_cmp O_cmp + g_sel O_sel + g_win O_win
+template <typename T>
+__global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) {
+    __shared__ float sqp[4][256];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= P.R) return;
+    const T *Qr = (const T *)P.Q + row * P.h * P.Dk;
+    for (int dk = lane; dk < P.Dk; dk += 64) {
+        float a = 0.f;
+        for (int hh = 0; hh < P.h; ++hh) a += Elt<T>::to_f(Qr[hh * P.Dk + dk]);
+        sqp[wave][dk] = rnd<T>(a / (float)P.h);
+    }
+    wave_lds_fence();
+    float act = 0.f;
+    if (lane < P.Hd) {
+        const T *w1 = (const T *)P.w1 + (int64_t)lane * P.Dk;
+        float a = 0.f;
+        for (int dk = 0; dk < P.Dk; ++dk) a = fmaf(Elt<T>::to_f(w1[dk]), sqp[wave][dk], a);
+        a = rnd<T>(a + Elt<T>::to_f(((const T *)P.b1)[lane]));
+        act = rnd<T>(a / (1.f + expf(-a)));  // silu
+    }
+    float gl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float part = lane < P.Hd ? Elt<T>::to_f(((const T *)P.w2)[k * P.Hd + lane]) * act : 0.f;
+        gl[k] = rnd<T>(wave_sum(part) + Elt<T>::to_f(((const T *)P.b2)[k]));
+        gl[k] = rnd<T>(gl[k] / fmaxf(P.tau, 1e-6f));
+    }
+    const float mx = fmaxf(gl[0], fmaxf(gl[1], gl[2]));
+    float pr[3];
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pr[k] = expf(gl[k] - mx);
+        den += pr[k];
+    }
+    int arg = 0;
+    if (gl[1] > gl[arg]) arg = 1;
+    if (gl[2] > gl[arg]) arg = 2;
+    float second = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k != arg) second = fmaxf(second, gl[k]);
+    const bool peaked = (gl[arg] - second) > 50.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pr[k] = peaked ? (k == arg ? 1.f : 0.f) : rnd<T>(pr[k] / den);
+    if (P.gates_out && lane < 3) P.gates_out[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
+    const int64_t base = row * P.h * P.Dv;
+    const T *Oc = (const T *)P.O_cmp + base, *Os = (const T *)P.O_sel + base, *Ow = (const T *)P.O_win + base;
+    T *Oo = (T *)P.O_out + base;
+    for (int e = lane; e < P.h * P.Dv; e += 64) {
+        const float t1 = rnd<T>(pr[0] * Elt<T>::to_f(Oc[e])), t2 = rnd<T>(pr[1] * Elt<T>::to_f(Os[e]));
+        const float t3 = rnd<T>(t1 + t2), t4 = rnd<T>(pr[2] * Elt<T>::to_f(Ow[e]));
+        Oo[e] = Elt<T>::from_f(t3 + t4);
+    }
+}
+
+int launch_gate_combine(const GateCombineParams &P, int dtype, hipStream_t st) {
+    if (P.R == 0) return NSA_OK;
+    NSA_CHECK_ARG(P.Dk <= 256 && P.Hd >= 1 && P.Hd <= 64, "gate_combine: Dk <= 256 and 1 <= hidden <= 64 supported");
+    const dim3 grid((unsigned)((P.R + 3) / 4)), block(256);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(gate_combine_kernel<float>, grid, block, 0, st, P);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(gate_combine_kernel<__bf16>, grid, block, 0, st, P);
+    else hipLaunchKernelGGL(gate_combine_kernel<_Float16>, grid, block, 0, st, P);
+    NSA_LAUNCH_CHECK("gate_combine");
+    return NSA_OK;
+}
+
+}  // namespace nsa

@@ -1,0 +1,35 @@
+// Argument blocks + launchers of the layer-level kernels (layer_fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsa {
+
+struct RopeAppendParams {
+    const void *proj;  // [B*S, NQ + 3 G Dk + 3 G Dv]: Q | K_sel | V_sel | K_win | V_win | K_raw | V_raw
+    void *Q_out;       // [B*S, NQ]
+    void *cache[6];    // K_sel, V_sel, K_win, V_win, K_raw, V_raw: [B,G,S_max,D] contiguous
+    int B, S, G, h, Dk, Dv, S_max, t0;
+    float rope_base, inv_scale;
+};
+struct CmpPoolParams {
+    const void *K_raw, *V_raw;  // [nbg, S_max, D]
+    void *K_cmp, *V_cmp;        // [nbg, n_cmp_max, D]
+    int nbg, S_max, n_cmp_max, Dk, Dv, l, d, j0, j1;
+    float rope_base, inv_scale;
+};
+struct GateCombineParams {
+    const void *Q, *O_cmp, *O_sel, *O_win;
+    void *O_out;
+    float *gates_out;  // [R,3] or null
+    const void *w1, *b1, *w2, *b2;
+    int64_t R;
+    int h, Dk, Dv, Hd;
+    float tau;
+};
+int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
+int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st);
+int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st);
+int launch_gate_combine(const GateCombineParams &P, int dtype, hipStream_t st);
+
+}  // namespace nsa

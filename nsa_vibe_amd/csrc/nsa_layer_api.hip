@@ -1,0 +1,166 @@
+// C ABI of the layer-level entry points (include/nsa_sel_hip.h, "Layer-level entry points").
+#include <cmath>
+
+#include "nsa_common.hpp"
+#include "layer_fused.hpp"
+
+using namespace nsa;
+
+static bool dt_ok(int dt) { return dt == NSA_DT_F32 || dt == NSA_DT_BF16 || dt == NSA_DT_F16; }
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t esize(int dt) { return dt == NSA_DT_F32 ? 4 : 2; }
+
+static int check_layer(const nsa_layer_desc *L, const char *who) {
+    NSA_CHECK_ARG(L, "%s: null layer descriptor", who);
+    NSA_CHECK_ARG(dt_ok(L->dtype), "%s: unknown dtype %d", who, L->dtype);
+    NSA_CHECK_ARG(L->dim >= 1 && L->G >= 1 && L->h >= 1 && L->Dk >= 2 && L->Dv >= 1 && L->Dk % 2 == 0 && L->Dv % 2 == 0,
+                  "%s: bad geometry (Dk, Dv must be even)", who);
+    NSA_CHECK_ARG(L->l >= 1 && L->d >= 1 && L->l_sel >= 1 && L->n_sel >= 1 && L->w >= 0, "%s: bad block parameters", who);
+    return NSA_OK;
+}
+static int check_kv(const nsa_kv_desc *kv, const char *who) {
+    NSA_CHECK_ARG(kv && kv->K_sel && kv->V_sel && kv->K_win && kv->V_win && kv->K_raw && kv->V_raw && kv->K_cmp && kv->V_cmp,
+                  "%s: null cache pointer", who);
+    NSA_CHECK_ARG(kv->B >= 1 && kv->S_max >= 1 && kv->n_cmp_max >= 1, "%s: bad cache sizes", who);
+    return NSA_OK;
+}
+
+extern "C" {
+
+int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, void *stream) {
+    NSA_CHECK_ARG(dt_ok(dtype), "linear_small: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(M >= 0 && N >= 0 && K >= 1, "linear_small: bad sizes");
+    if (M == 0 || N == 0) return NSA_OK;
+    NSA_CHECK_ARG(A && W && out, "linear_small: null pointer");
+    return launch_linear_small(A, W, out, M, N, K, dtype, (hipStream_t)stream);
+}
+
+int nsa_rope_cache_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, void *Q_out, int S, int t0,
+                          void *stream) {
+    if (int rc = check_layer(L, "rope_cache_append")) return rc;
+    if (int rc = check_kv(kv, "rope_cache_append")) return rc;
+    NSA_CHECK_ARG(S >= 0 && t0 >= 0 && t0 + S <= kv->S_max, "rope_cache_append: tokens [%d,%d) exceed the cache capacity %d", t0, t0 + S,
+                  kv->S_max);
+    if (S == 0) return NSA_OK;
+    NSA_CHECK_ARG(proj && Q_out, "rope_cache_append: null pointer");
+    RopeAppendParams P{};
+    P.proj = proj;
+    P.Q_out = Q_out;
+    P.cache[0] = kv->K_sel; P.cache[1] = kv->V_sel; P.cache[2] = kv->K_win; P.cache[3] = kv->V_win; P.cache[4] = kv->K_raw; P.cache[5] = kv->V_raw;
+    P.B = kv->B; P.S = S; P.G = L->G; P.h = L->h; P.Dk = L->Dk; P.Dv = L->Dv; P.S_max = kv->S_max; P.t0 = t0;
+    P.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
+    P.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    return launch_rope_cache_append(P, L->dtype, (hipStream_t)stream);
+}
+
+int nsa_cmp_pool_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, int j0, int j1, void *stream) {
+    if (int rc = check_layer(L, "cmp_pool_append")) return rc;
+    if (int rc = check_kv(kv, "cmp_pool_append")) return rc;
+    NSA_CHECK_ARG(j0 >= 0 && j1 >= j0 && j1 <= kv->n_cmp_max, "cmp_pool_append: tokens [%d,%d) exceed n_cmp_max %d", j0, j1, kv->n_cmp_max);
+    NSA_CHECK_ARG(j1 == j0 || (int64_t)(j1 - 1) * L->d + L->l <= kv->S_max, "cmp_pool_append: window past the cache capacity");
+    CmpPoolParams P{};
+    P.K_raw = kv->K_raw; P.V_raw = kv->V_raw; P.K_cmp = kv->K_cmp; P.V_cmp = kv->V_cmp;
+    P.nbg = kv->B * L->G; P.S_max = kv->S_max; P.n_cmp_max = kv->n_cmp_max; P.Dk = L->Dk; P.Dv = L->Dv; P.l = L->l; P.d = L->d;
+    P.j0 = j0; P.j1 = j1;
+    P.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
+    P.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    return launch_cmp_pool(P, L->dtype, (hipStream_t)stream);
+}
+
+int nsa_gate_combine(const nsa_layer_desc *L, const void *Q, const void *O_cmp, const void *O_sel, const void *O_win, void *O_out,
+                     float *gates_out, int64_t R, void *stream) {
+    if (int rc = check_layer(L, "gate_combine")) return rc;
+    NSA_CHECK_ARG(R >= 0, "gate_combine: negative size");
+    if (R == 0) return NSA_OK;
+    NSA_CHECK_ARG(Q && O_cmp && O_sel && O_win && O_out && L->gate_w1 && L->gate_b1 && L->gate_w2 && L->gate_b2, "gate_combine: null pointer");
+    GateCombineParams P{};
+    P.Q = Q; P.O_cmp = O_cmp; P.O_sel = O_sel; P.O_win = O_win; P.O_out = O_out; P.gates_out = gates_out;
+    P.w1 = L->gate_w1; P.b1 = L->gate_b1; P.w2 = L->gate_w2; P.b2 = L->gate_b2;
+    P.R = R; P.h = L->h; P.Dk = L->Dk; P.Dv = L->Dv; P.Hd = L->gate_hidden; P.tau = L->gate_tau;
+    return launch_gate_combine(P, L->dtype, (hipStream_t)stream);
+}
+
+// workspace: proj | Q | O_cmp | O_sel | O_win | O_mix | ranges | selection-decode scratch | band scratch
+struct DecodeWs {
+    size_t proj, q, ocmp, osel, owin, omix, ranges, sel, band, total, sel_bytes, band_bytes;
+};
+static DecodeWs decode_ws(const nsa_layer_desc *L, int B, int S_max) {
+    DecodeWs w;
+    const size_t e = esize(L->dtype);
+    const size_t NQ = (size_t)L->G * L->h * L->Dk, NO = (size_t)L->G * L->h * L->Dv;
+    const size_t NT = NQ + 3 * (size_t)L->G * L->Dk + 3 * (size_t)L->G * L->Dv;
+    const int n_cmp_max = S_max < L->l ? 0 : (S_max - L->l) / L->d + 1;
+    const int S_sel_max = (S_max + L->l_sel - 1) / L->l_sel + 1;
+    size_t o = 0;
+    w.proj = o; o += up256(B * NT * e);
+    w.q = o; o += up256(B * NQ * e);
+    w.ocmp = o; o += up256(B * NO * e);
+    w.osel = o; o += up256(B * NO * e);
+    w.owin = o; o += up256(B * NO * e);
+    w.omix = o; o += up256(B * NO * e);
+    w.ranges = o; o += up256(sizeof(int32_t) * (size_t)B * L->G * L->n_sel * 2);
+    w.sel_bytes = nsa_sel_decode_step_workspace(B, L->G, L->h, L->Dk, L->Dv, n_cmp_max, S_sel_max, L->n_sel, L->dtype);
+    w.sel = o; o += up256(w.sel_bytes);
+    w.band_bytes = nsa_band_attn_fwd_workspace(B, 1, L->G, L->h, L->Dk, L->Dv, L->dtype);
+    w.band = o; o += up256(w.band_bytes);
+    w.total = o;
+    return w;
+}
+
+size_t nsa_layer_decode_step_workspace(const nsa_layer_desc *L, int B, int S_max) {
+    if (!L || !dt_ok(L->dtype) || B < 1 || S_max < 1) return 0;
+    return decode_ws(L, B, S_max).total;
+}
+
+int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
+                          const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_layer(L, "layer_decode_step")) return rc;
+    if (int rc = check_kv(kv, "layer_decode_step")) return rc;
+    NSA_CHECK_ARG(x && y && L->W_qkv && L->W_out, "layer_decode_step: null pointer");
+    NSA_CHECK_ARG(t >= 0 && t < kv->S_max, "layer_decode_step: position %d outside the cache capacity %d", t, kv->S_max);
+    NSA_CHECK_ARG(S_sel >= 1 && (int64_t)S_sel * L->l_sel >= t + 1, "layer_decode_step: block metadata (S_sel=%d) does not cover token %d", S_sel, t);
+    const int B = kv->B;
+    const DecodeWs W = decode_ws(L, B, kv->S_max);
+    NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 256 == 0) && workspace_bytes >= W.total,
+                  "layer_decode_step: workspace missing, misaligned or too small");
+    unsigned char *ws = (unsigned char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = L->dtype;
+    const int G = L->G, h = L->h, Dk = L->Dk, Dv = L->Dv;
+    const int NQ = G * h * Dk, NO = G * h * Dv, NT = NQ + 3 * G * Dk + 3 * G * Dv;
+    void *proj = ws + W.proj, *Q = ws + W.q, *Ocmp = ws + W.ocmp, *Osel = ws + W.osel, *Owin = ws + W.owin, *Omix = ws + W.omix;
+    int32_t *ranges = ranges_out ? ranges_out : (int32_t *)(ws + W.ranges);
+
+    // 1. fused QKV projection, 2. RoPE + cache append at position t
+    if (int rc = launch_linear_small(x, L->W_qkv, proj, B, NT, L->dim, dt, st)) return rc;
+    if (int rc = nsa_rope_cache_append(L, kv, proj, Q, 1, t, stream)) return rc;
+    // 3. emit a compressed token when a window completes (nsa_attention.py:588-604)
+    const int S_raw = t + 1;
+    const int n_cmp = S_raw < L->l ? 0 : (S_raw - L->l) / L->d + 1;
+    if (S_raw >= L->l && (S_raw - L->l) % L->d == 0)
+        if (int rc = nsa_cmp_pool_append(L, kv, n_cmp - 1, n_cmp, stream)) return rc;
+    NSA_CHECK_ARG(n_cmp <= kv->n_cmp_max, "layer_decode_step: compressed cache too small");
+    // 4. selected branch
+    const int64_t ksb = (int64_t)G * kv->S_max * Dk, ksg = (int64_t)kv->S_max * Dk;
+    const int64_t vsb = (int64_t)G * kv->S_max * Dv, vsg = (int64_t)kv->S_max * Dv;
+    const int64_t kcb = (int64_t)G * kv->n_cmp_max * Dk, kcg = (int64_t)kv->n_cmp_max * Dk;
+    const int64_t vcb = (int64_t)G * kv->n_cmp_max * Dv, vcg = (int64_t)kv->n_cmp_max * Dv;
+    const float scale = 1.0f / sqrtf((float)Dk);
+    if (int rc = nsa_sel_decode_step(Q, kv->K_cmp, kv->K_sel, kv->V_sel, csc_ptr, csc_rows, csc_vals, ranges, Osel, B, G, h, Dk, Dv, n_cmp,
+                                     S_sel, S_raw, L->l, L->d, L->l_sel, L->n_sel, t, kcb, kcg, Dk, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale,
+                                     ws + W.sel, W.sel_bytes, stream))
+        return rc;
+    // 5. sliding and compressed branches
+    if (int rc = nsa_band_attn_fwd(Q, kv->K_win, kv->V_win, Owin, nullptr, B, 1, G, h, Dk, Dv, S_raw, ksb, ksg, Dk, vsb, vsg, Dv, t, 0, 1, 0,
+                                   L->w, dt, scale, 0, ws + W.band, W.band_bytes, stream))
+        return rc;
+    if (int rc = nsa_band_attn_fwd(Q, kv->K_cmp, kv->V_cmp, Ocmp, nullptr, B, 1, G, h, Dk, Dv, n_cmp, kcb, kcg, Dk, vcb, vcg, Dv, t, L->l, L->d,
+                                   1, 1 << 30, dt, scale, 0, ws + W.band, W.band_bytes, stream))
+        return rc;
+    // 6. gates + combine, 7. output projection
+    if (int rc = nsa_gate_combine(L, Q, Ocmp, Osel, Owin, Omix, gates_out, (int64_t)B * G, stream)) return rc;
+    return launch_linear_small(Omix, L->W_out, y, B, L->dim, NO, dt, st);
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@ Selector semantics: `selector="sequential"` (reference default prefill, :1521-17
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from typing import Optional
@@ -25,10 +26,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from .band_attention import batched_causal_attention_compressed, sliding_window_attention
 from .kv_cache import NSA_KV
 from .selection_attention import selection_attention_hip, selection_decode_step
-from .selection_scorer import select_topn_ranges_batched, select_topn_ranges_rows, selection_scores
+from .selection_scorer import _DT, _stream, select_topn_ranges_batched, select_topn_ranges_rows, selection_scores, workspace
 
 
 def apply_rope(x: torch.Tensor, pos: torch.Tensor, base: float = 10000.0, scale: float = 1.0) -> torch.Tensor:
@@ -140,6 +142,44 @@ class NSAAttention(nn.Module):
         return {"k_mean": float(L.float().mean()) if L.numel() else 0.0, "k_max": k_max, "rows": int(L.numel()),
                 "pct_at_max": float((L == k_max).float().mean()) if k_max > 0 else 0.0, "l_sel": self.l_sel, "n_sel": self.n_sel}
 
+    # ---- native layer path (inference): descriptors for the C ABI ------------------------------
+    _QKV = ("W_Q", "W_K_sel", "W_V_sel", "W_K_win", "W_V_win", "W_K_cmp", "W_V_cmp")
+
+    def _native_ok(self, x: torch.Tensor) -> bool:
+        """the fused kernels cover inference (no autograd graph) on the GPU; training keeps the differentiable eager ops"""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        return x.is_cuda and x.dtype in _DT and self.W_Q.weight.dtype == x.dtype and self.gate.fc1.out_features <= 64
+
+    def _layer_desc(self):
+        """(nsa_layer_desc, fused W_qkv) -- rebuilt when a parameter was modified or moved (tensor version counters)"""
+        ps = [getattr(self, n).weight for n in self._QKV] + [self.out.weight, self.gate.fc1.weight, self.gate.fc1.bias,
+                                                               self.gate.fc2.weight, self.gate.fc2.bias]
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+        if getattr(self, "_desc_key", None) != key:
+            W_qkv = torch.cat([p.detach() for p in ps[:7]], dim=0).contiguous()
+            keep = [W_qkv] + [p.detach().contiguous() for p in ps[7:]]
+            d = _lib.NsaLayerDesc()
+            d.dim, d.G, d.h, d.Dk, d.Dv = self.dim, self.n_kv_groups, self.h_per_group, self.d_k, self.d_v
+            d.l, d.d, d.l_sel, d.n_sel, d.w = self.l, self.d, self.l_sel, self.n_sel, self.w
+            d.gate_hidden, d.dtype = self.gate.fc1.out_features, _DT[W_qkv.dtype]
+            d.rope_base, d.rope_scale, d.gate_tau = 10000.0, self.rope_scale, float(self.gate_temp)
+            d.W_qkv, d.W_out = keep[0].data_ptr(), keep[1].data_ptr()
+            d.gate_w1, d.gate_b1, d.gate_w2, d.gate_b2 = (k.data_ptr() for k in keep[2:])
+            self._desc_key, self._desc, self._desc_keep = key, d, keep
+        return self._desc, self._desc_keep[0]
+
+    @staticmethod
+    def _kv_desc(kv: NSA_KV):
+        d = getattr(kv, "_desc", None)
+        if d is None:
+            d = _lib.NsaKvDesc()
+            d.K_sel, d.V_sel, d.K_win, d.V_win = kv._K_sel.data_ptr(), kv._V_sel.data_ptr(), kv._K_win.data_ptr(), kv._V_win.data_ptr()
+            d.K_raw, d.V_raw, d.K_cmp, d.V_cmp = kv._K_raw.data_ptr(), kv._V_raw.data_ptr(), kv._K_cmp.data_ptr(), kv._V_cmp.data_ptr()
+            d.B, d.S_max, d.n_cmp_max = kv.B, kv._K_sel.shape[2], kv._K_cmp.shape[2]
+            kv._desc = d
+        return d
+
     # ---- helpers ---------------------------------------------------------------------------
     def _project(self, x: torch.Tensor, pos: torch.Tensor):
         B, S, _ = x.shape
@@ -170,11 +210,28 @@ class NSAAttention(nn.Module):
     def _prefill(self, x: torch.Tensor, kv: NSA_KV):
         B, S, _ = x.shape
         assert kv.t == 0, "prefill expects an empty cache"
-        pos = torch.arange(S, device=x.device)
-        Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = self._project(x, pos)
-        kv.write_tokens(K_sel, V_sel, K_win, V_win, K_raw, V_raw)
-        K_cmp, V_cmp = avg_pool_phi(apply_rope(K_raw, pos), V_raw, self.l, self.d)
-        kv.write_compressed(K_cmp, V_cmp, at=0)
+        native = self._native_ok(x)
+        if native:
+            # one fused projection GEMM, then RoPE + cache append and the compressed-token pooling as native kernels
+            if S > kv._K_sel.shape[2]:
+                raise RuntimeError(f"NSA_KV capacity exceeded: {S} > S_max={kv.S_max}")
+            L, dev = _lib.lib(), x.device
+            desc, W_qkv = self._layer_desc()
+            kd = self._kv_desc(kv)
+            proj = F.linear(x, W_qkv)
+            Q = torch.empty((B, S, self.n_kv_groups, self.h_per_group, self.d_k), dtype=x.dtype, device=dev)
+            _lib.check(L.nsa_rope_cache_append(ctypes.byref(desc), ctypes.byref(kd), proj.data_ptr(), Q.data_ptr(), S, 0, _stream(dev)),
+                       "nsa_rope_cache_append")
+            kv.t = S
+            n_cmp = 0 if S < self.l else (S - self.l) // self.d + 1
+            _lib.check(L.nsa_cmp_pool_append(ctypes.byref(desc), ctypes.byref(kd), 0, n_cmp, _stream(dev)), "nsa_cmp_pool_append")
+            kv.n_cmp = n_cmp
+        else:
+            pos = torch.arange(S, device=x.device)
+            Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = self._project(x, pos)
+            kv.write_tokens(K_sel, V_sel, K_win, V_win, K_raw, V_raw)
+            K_cmp, V_cmp = avg_pool_phi(apply_rope(K_raw, pos), V_raw, self.l, self.d)
+            kv.write_compressed(K_cmp, V_cmp, at=0)
         meta = kv.ensure_meta(S)
         scale = 1.0 / math.sqrt(self.d_k)
         Qc = Q.contiguous()
@@ -189,9 +246,48 @@ class NSAAttention(nn.Module):
         # ---- compressed + sliding branches (HIP band kernel)
         O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, scale=scale)
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S], kv._V_win[:, :, :S], self.w, scale=scale)
+        if native:
+            O = torch.empty_like(O_sel)
+            gates = torch.empty((B, S, self.n_kv_groups, 3), dtype=torch.float32, device=x.device)
+            _lib.check(L.nsa_gate_combine(ctypes.byref(desc), Qc.data_ptr(), O_cmp.data_ptr(), O_sel.data_ptr(), O_win.data_ptr(),
+                                          O.data_ptr(), gates.data_ptr(), B * S * self.n_kv_groups, _stream(dev)), "nsa_gate_combine")
+            self._last_gates = gates
+            return self.out(O.reshape(B, S, self.n_heads * self.d_v)), kv
         return self._combine(Q, O_cmp, O_sel, O_win), kv
 
+    def _decode_native(self, x: torch.Tensor, kv: NSA_KV):
+        """the whole decode step in one native call (nsa_layer_decode_step): ~15 kernel launches, no host sync"""
+        t, B, dev = kv.t, x.shape[0], x.device
+        if t + 1 > kv._K_sel.shape[2]:
+            raise RuntimeError(f"NSA_KV capacity exceeded: {t}+1 > S_max={kv.S_max}")
+        if kv.meta.S_sel == 0:  # block metadata refresh policy of the reference (:606-632)
+            kv.ensure_meta(max(t + 1, self.l_sel))
+        elif t + 1 > kv.meta.S_sel * self.l_sel:
+            kv.ensure_meta(t + 1)
+        S_raw = t + 1
+        num_cmp = 0 if S_raw < self.l else (S_raw - self.l) // self.d + 1
+        L = _lib.lib()
+        desc, _ = self._layer_desc()
+        kd = self._kv_desc(kv)
+        ws = workspace(dev, L.nsa_layer_decode_step_workspace(ctypes.byref(desc), B, kd.S_max) + 256, "layer_decode")
+        wptr = (ws.data_ptr() + 255) & ~255
+        cptr, crows, cvals = kv.meta.device_csc(dev)
+        xc = x.reshape(B, self.dim).contiguous()
+        y = torch.empty((B, 1, self.dim), dtype=x.dtype, device=dev)
+        ranges = torch.empty((B, self.n_kv_groups, self.n_sel, 2), dtype=torch.int32, device=dev)
+        gates = torch.empty((B, 1, self.n_kv_groups, 3), dtype=torch.float32, device=dev)
+        rc = L.nsa_layer_decode_step(ctypes.byref(desc), ctypes.byref(kd), xc.data_ptr(), y.data_ptr(), t, cptr.data_ptr(),
+                                     crows.data_ptr(), cvals.data_ptr(), int(kv.meta.S_sel), ranges.data_ptr(), gates.data_ptr(),
+                                     wptr, ws.numel() - (wptr - ws.data_ptr()), _stream(dev))
+        _lib.check(rc, "nsa_layer_decode_step")
+        kv.t, kv.n_cmp = S_raw, num_cmp
+        kv.append_reads(num_cmp, S_raw)
+        self._last_ranges, self._last_gates = ranges, gates
+        return y, kv
+
     def _decode(self, x: torch.Tensor, kv: NSA_KV):
+        if self._native_ok(x):
+            return self._decode_native(x, kv)
         t = kv.t  # position of the new token
         pos = torch.tensor([t], device=x.device)
         Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = self._project(x, pos)
