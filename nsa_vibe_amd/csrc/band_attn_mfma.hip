@@ -18,7 +18,7 @@
 namespace nsa {
 
 template <typename T, int NT, bool SPLIT>
-__global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
+__device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const unsigned bid) {
     using M = MfmaT<T>;
     using G_ = Geo<64>;
     using x8 = typename M::x8;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
     const int nbg = P.B * P.G;
     int bg, grp, sp = 0;
     if (SPLIT) {
-        const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+        const int64_t wid = (int64_t)bid * 4 + wave;
         const int64_t gi = wid / P.nsplit;
         sp = (int)(wid - gi * P.nsplit);
         bg = (int)(gi / ngrp);
@@ -42,12 +42,12 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
         const int W = (ngrp + 3) >> 2;  // workgroups per (b,g)
         int tc;
         if (P.map_mode == 2) {  // whole (b,g) pairs per XCD (workgroups go round-robin over the 8 XCDs)
-            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            const int xcd = bid & 7, idx = bid >> 3;
             bg = (idx / W) * 8 + xcd;
             tc = idx % W;
         } else {
-            bg = blockIdx.x / W;
-            tc = blockIdx.x % W;
+            bg = bid / W;
+            tc = bid % W;
         }
         grp = 4 * tc + wave;
         if (grp >= ngrp || bg >= nbg) return;
@@ -270,6 +270,18 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
     }
 }
 
+template <typename T, int NT, bool SPLIT>
+__global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
+    band_attn_body<T, NT, SPLIT>(P, blockIdx.x);
+}
+
+// decode: the sliding and the compressed branch of one step in ONE launch (two argument blocks, split-KV form)
+template <typename T>
+__global__ __launch_bounds__(256) void band_attn_fwd_dual_kernel(BandAttnParams P0, BandAttnParams P1, unsigned grid0) {
+    if (blockIdx.x < grid0) band_attn_body<T, 1, true>(P0, blockIdx.x);
+    else band_attn_body<T, 1, true>(P1, blockIdx.x - grid0);
+}
+
 // ---- host side ----------------------------------------------------------------------------
 bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv) {
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
@@ -315,6 +327,7 @@ static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
         const int64_t waves = nbg * ngrp * P.nsplit;
         hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st, P);
         NSA_LAUNCH_CHECK("band_attn_fwd(split)");
+        if (P.defer_combine) return NSA_OK;
         SelAttnParams C{};
         C.O = P.O;
         C.lse = P.lse;
@@ -347,6 +360,24 @@ int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st
                   "band MFMA kernel: one (b,g) K/V slab must be smaller than 2 GiB (buffer addressing)");
     if (dtype == NSA_DT_BF16) return launch_band_t<__bf16>(P, st);
     return launch_band_t<_Float16>(P, st);
+}
+
+// Both branches of a decode step in one launch.  Requires both to be in split form with deferred combine (the caller combines).
+int launch_band_attn_fwd_dual(const BandAttnParams &A0, const BandAttnParams &A1, int dtype, hipStream_t st) {
+    BandAttnParams P[2] = {A0, A1};
+    unsigned grid[2];
+    for (int i = 0; i < 2; ++i) {
+        int nt = 1, ns = 1;
+        band_plan(P[i].B, P[i].S, P[i].G, P[i].h, &nt, &P[i].tpw, &ns);
+        NSA_CHECK_ARG(nt == 1 && ns > 1 && P[i].part && P[i].nsplit == ns && P[i].defer_combine, "band dual launch: split form required");
+        const int64_t waves = (int64_t)P[i].B * P[i].G * ((P[i].S + P[i].tpw - 1) / P[i].tpw) * ns;
+        grid[i] = (unsigned)((waves + 3) / 4);
+    }
+    const size_t lds = 4 * (size_t)(2 * Geo<64>::TILE_BYTES);
+    if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(band_attn_fwd_dual_kernel<__bf16>, dim3(grid[0] + grid[1]), dim3(256), lds, st, P[0], P[1], grid[0]);
+    else hipLaunchKernelGGL(band_attn_fwd_dual_kernel<_Float16>, dim3(grid[0] + grid[1]), dim3(256), lds, st, P[0], P[1], grid[0]);
+    NSA_LAUNCH_CHECK("band_attn_fwd_dual");
+    return NSA_OK;
 }
 
 }  // namespace nsa

@@ -7,7 +7,7 @@
 //   * gate MLP + 3-branch combine (nsa_attention.py:32-82, 85-124)
 // Arithmetic follows the PyTorch operator chain the reference runs, including where it rounds to the activation dtype
 // (rnd() below), so a bf16 module gives the same numbers whether these kernels or the eager ops are used.
-#include "nsa_common.hpp"
+#include "attn_mfma_tiles.hpp"
 #include "layer_fused.hpp"
 
 namespace nsa {
@@ -32,6 +32,30 @@ __device__ __forceinline__ void rope_pair(float x0, float x1, int i, int D, floa
 }
 
 // ------------------------------------------------------------------------------------------ small-M linear
+// 8 consecutive elements as floats (16-byte loads when `vec`, i.e. K % 8 == 0 and 16-byte aligned rows)
+template <typename T>
+__device__ __forceinline__ void load8(const T *p, int nvalid, bool vec, float (&out)[8]) {
+    if (vec) {
+        if constexpr (sizeof(T) == 2) {
+            const u32x4 raw = *(const u32x4 *)p;
+            const T *e = (const T *)&raw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = Elt<T>::to_f(e[j]);
+        } else {
+            const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                out[j] = a[j];
+                out[4 + j] = b[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = j < nvalid ? Elt<T>::to_f(p[j]) : 0.f;
+    }
+}
+
+// one wave per output column n (W row n stays in registers), rows of A in chunks of 8
 template <typename T>
 __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M,
                                                            int N, int K) {
@@ -39,18 +63,17 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const T *w = W + (int64_t)n * K;
+    const bool vec = (K % 8 == 0) && (((uintptr_t)A | (uintptr_t)W) % 16 == 0);
     for (int m0 = 0; m0 < M; m0 += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int mm = min(8, M - m0);
         for (int k = lane * 8; k < K; k += 512) {
-            float wv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wv[j] = (k + j < K) ? Elt<T>::to_f(w[k + j]) : 0.f;
+            float wv[8], av[8];
+            load8<T>(w + k, K - k, vec, wv);
             for (int r = 0; r < mm; ++r) {
-                const T *a = A + (int64_t)(m0 + r) * K + k;
+                load8<T>(A + (int64_t)(m0 + r) * K + k, K - k, vec, av);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (k + j < K) acc[r] = fmaf(wv[j], Elt<T>::to_f(a[j]), acc[r]);
+                for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], av[j], acc[r]);
             }
         }
         for (int r = 0; r < mm; ++r) {
@@ -107,6 +130,80 @@ __global__ __launch_bounds__(256) void rope_cache_append_kernel(RopeAppendParams
         dst[0] = Elt<T>::from_f(x0);
         dst[1] = Elt<T>::from_f(x1);
     }
+}
+
+// decode form: the fused QKV projection and the RoPE + cache append in one kernel.  One wave per PAIR of adjacent output
+// columns (a rotation pair), rows of x in chunks of 8; lane r of the wave finishes row r of the chunk.
+template <typename T>
+__device__ __forceinline__ void rope_store_pair(const RopeAppendParams &P, int b, int s, int col, float x0, float x1) {
+    const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
+    const float pos = (float)(P.t0 + s);
+    if (col < NQ) {
+        rope_pair<T>(x0, x1, col >> 1, NQ, pos, P.rope_base, P.inv_scale, x0, x1);
+        T *dst = (T *)P.Q_out + ((int64_t)b * P.S + s) * NQ + col;
+        dst[0] = Elt<T>::from_f(x0);
+        dst[1] = Elt<T>::from_f(x1);
+        return;
+    }
+    int c = col - NQ;
+    const int pairw = GK + GV;
+    const int sp = c / pairw;
+    c -= sp * pairw;
+    const bool isv = c >= GK;
+    if (isv) c -= GK;
+    const int D = isv ? P.Dv : P.Dk;
+    const int g = c / D, dc = c - g * D;
+    if (!isv && sp < 2) rope_pair<T>(x0, x1, dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, x0, x1);
+    T *dst = (T *)P.cache[2 * sp + (isv ? 1 : 0)] + (((int64_t)b * P.G + g) * P.S_max + (P.t0 + s)) * D + dc;
+    dst[0] = Elt<T>::from_f(x0);
+    dst[1] = Elt<T>::from_f(x1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W, int K) {
+    const int lane = lane_id();
+    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (2 * pair >= NT) return;
+    const T *w0 = W + (int64_t)(2 * pair) * K, *w1 = w0 + K;
+    const bool vec = (K % 8 == 0) && (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
+    const int M = P.B;  // S == 1
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float a0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int mm = min(8, M - m0);
+        for (int k = lane * 8; k < K; k += 512) {
+            float u0[8], u1[8], xv[8];
+            load8<T>(w0 + k, K - k, vec, u0);
+            load8<T>(w1 + k, K - k, vec, u1);
+            for (int r = 0; r < mm; ++r) {
+                load8<T>(X + (int64_t)(m0 + r) * K + k, K - k, vec, xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a0[r] = fmaf(u0[j], xv[j], a0[r]);
+                    a1[r] = fmaf(u1[j], xv[j], a1[r]);
+                }
+            }
+        }
+        float x0 = 0.f, x1 = 0.f;
+        for (int r = 0; r < mm; ++r) {
+            const float s0 = wave_sum(a0[r]), s1 = wave_sum(a1[r]);
+            if (lane == r) {
+                x0 = rnd<T>(s0);  // the projection output in the activation dtype, as the separate GEMM leaves it
+                x1 = rnd<T>(s1);
+            }
+        }
+        if (lane < mm) rope_store_pair<T>(P, m0 + lane, 0, 2 * pair, x0, x1);
+    }
+}
+
+int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st) {
+    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    const dim3 grid((unsigned)((NT / 2 + 3) / 4)), block(256);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(qkv_rope_append_kernel<float>, grid, block, 0, st, P, (const float *)X, (const float *)W, K);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(qkv_rope_append_kernel<__bf16>, grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K);
+    else hipLaunchKernelGGL(qkv_rope_append_kernel<_Float16>, grid, block, 0, st, P, (const _Float16 *)X, (const _Float16 *)W, K);
+    NSA_LAUNCH_CHECK("qkv_rope_append");
+    return NSA_OK;
 }
 
 int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st) {
@@ -166,36 +263,33 @@ int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st) {
 // ------------------------------------------------------------------------------------------ gate MLP + combine
 // one wave per (b, s, g) row: q_pooled = mean_h Q -> fc1 -> silu -> fc2 -> / tau -> softmax (one-hot when the top two
 // logits are more than 50 apart, nsa_attention.py:70-81) -> O = g_cmp O_cmp + g_sel O_sel + g_win O_win
+// gate probabilities of one row (wave-cooperative; sqp = 256 wave-private floats)
 template <typename T>
-__global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) {
-    __shared__ float sqp[4][256];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= P.R) return;
-    const T *Qr = (const T *)P.Q + row * P.h * P.Dk;
-    for (int dk = lane; dk < P.Dk; dk += 64) {
+__device__ __forceinline__ void gate_probs(const T *Qr, int h, int Dk, int Hd, const void *w1_, const void *b1_, const void *w2_,
+                                           const void *b2_, float tau, float *sqp, float (&pr)[3]) {
+    const int lane = lane_id();
+    for (int dk = lane; dk < Dk; dk += 64) {
         float a = 0.f;
-        for (int hh = 0; hh < P.h; ++hh) a += Elt<T>::to_f(Qr[hh * P.Dk + dk]);
-        sqp[wave][dk] = rnd<T>(a / (float)P.h);
+        for (int hh = 0; hh < h; ++hh) a += Elt<T>::to_f(Qr[hh * Dk + dk]);
+        sqp[dk] = rnd<T>(a / (float)h);
     }
     wave_lds_fence();
     float act = 0.f;
-    if (lane < P.Hd) {
-        const T *w1 = (const T *)P.w1 + (int64_t)lane * P.Dk;
+    if (lane < Hd) {
+        const T *w1 = (const T *)w1_ + (int64_t)lane * Dk;
         float a = 0.f;
-        for (int dk = 0; dk < P.Dk; ++dk) a = fmaf(Elt<T>::to_f(w1[dk]), sqp[wave][dk], a);
-        a = rnd<T>(a + Elt<T>::to_f(((const T *)P.b1)[lane]));
+        for (int dk = 0; dk < Dk; ++dk) a = fmaf(Elt<T>::to_f(w1[dk]), sqp[dk], a);
+        a = rnd<T>(a + Elt<T>::to_f(((const T *)b1_)[lane]));
         act = rnd<T>(a / (1.f + expf(-a)));  // silu
     }
     float gl[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float part = lane < P.Hd ? Elt<T>::to_f(((const T *)P.w2)[k * P.Hd + lane]) * act : 0.f;
-        gl[k] = rnd<T>(wave_sum(part) + Elt<T>::to_f(((const T *)P.b2)[k]));
-        gl[k] = rnd<T>(gl[k] / fmaxf(P.tau, 1e-6f));
+        const float part = lane < Hd ? Elt<T>::to_f(((const T *)w2_)[k * Hd + lane]) * act : 0.f;
+        gl[k] = rnd<T>(wave_sum(part) + Elt<T>::to_f(((const T *)b2_)[k]));
+        gl[k] = rnd<T>(gl[k] / fmaxf(tau, 1e-6f));
     }
     const float mx = fmaxf(gl[0], fmaxf(gl[1], gl[2]));
-    float pr[3];
     float den = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -212,15 +306,82 @@ __global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) 
     const bool peaked = (gl[arg] - second) > 50.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) pr[k] = peaked ? (k == arg ? 1.f : 0.f) : rnd<T>(pr[k] / den);
+}
+
+template <typename T>
+__device__ __forceinline__ float mix3(const float (&pr)[3], float oc, float os, float ow) {
+    const float t1 = rnd<T>(pr[0] * oc), t2 = rnd<T>(pr[1] * os);
+    const float t3 = rnd<T>(t1 + t2), t4 = rnd<T>(pr[2] * ow);
+    return t3 + t4;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) {
+    __shared__ float sqp[4][256];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= P.R) return;
+    float pr[3];
+    gate_probs<T>((const T *)P.Q + row * P.h * P.Dk, P.h, P.Dk, P.Hd, P.w1, P.b1, P.w2, P.b2, P.tau, sqp[wave], pr);
     if (P.gates_out && lane < 3) P.gates_out[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
     const int64_t base = row * P.h * P.Dv;
     const T *Oc = (const T *)P.O_cmp + base, *Os = (const T *)P.O_sel + base, *Ow = (const T *)P.O_win + base;
     T *Oo = (T *)P.O_out + base;
-    for (int e = lane; e < P.h * P.Dv; e += 64) {
-        const float t1 = rnd<T>(pr[0] * Elt<T>::to_f(Oc[e])), t2 = rnd<T>(pr[1] * Elt<T>::to_f(Os[e]));
-        const float t3 = rnd<T>(t1 + t2), t4 = rnd<T>(pr[2] * Elt<T>::to_f(Ow[e]));
-        Oo[e] = Elt<T>::from_f(t3 + t4);
+    for (int e = lane; e < P.h * P.Dv; e += 64)
+        Oo[e] = Elt<T>::from_f(mix3<T>(pr, Elt<T>::to_f(Oc[e]), Elt<T>::to_f(Os[e]), Elt<T>::to_f(Ow[e])));
+}
+
+// decode: split-KV combine of the three branches + gate + mix in one pass.  One wave per (row, head), Dv = 64 (lane = column).
+// Each branch arrives either as split-KV partial records (ns > 1, layout of sel_attn_combine_kernel) or final (ns == 1).
+template <typename T>
+__global__ __launch_bounds__(256) void decode_finish_kernel(DecodeFinishParams P) {
+    __shared__ float sqp[4][256];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= P.R * P.h) return;
+    const int64_t row = wid / P.h;
+    const int hh = (int)(wid - row * P.h);
+    constexpr int D = 64;
+    float o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ns = P.ns[i];
+        if (ns <= 1) {
+            o[i] = Elt<T>::to_f(((const T *)P.O[i])[wid * D + lane]);
+            continue;
+        }
+        const float *base = P.part[i] + ((row * ns) * (int64_t)P.h + hh) * (D + PART_PAD);
+        const int64_t sstride = (int64_t)P.h * (D + PART_PAD);
+        float m = -INFINITY, l = 0.f;
+        if (lane < ns) {
+            m = base[lane * sstride];
+            l = base[lane * sstride + 1];
+        }
+        const float mmax = wave_max(m);
+        const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mmax);
+        const float ltot = wave_sum(l * w);
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < ns) acc = fmaf(base[s * sstride + PART_PAD + lane], __shfl(w, s, 64), acc);
+        o[i] = rnd<T>(acc * (ltot > 0.f ? 1.f / ltot : 0.f));  // the branch output in the activation dtype, as its own combine pass leaves it
     }
+    float pr[3];
+    gate_probs<T>((const T *)P.Q + row * P.h * P.Dk, P.h, P.Dk, P.Hd, P.w1, P.b1, P.w2, P.b2, P.tau, sqp[wave], pr);
+    if (P.gates_out && hh == 0 && lane < 3) P.gates_out[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
+    ((T *)P.O_out)[wid * D + lane] = Elt<T>::from_f(mix3<T>(pr, o[0], o[1], o[2]));
+}
+
+int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st) {
+    if (P.R == 0) return NSA_OK;
+    NSA_CHECK_ARG(P.Dv == 64 && P.Dk <= 256 && P.Hd >= 1 && P.Hd <= 64, "decode_finish: Dv = 64, Dk <= 256, hidden <= 64 supported");
+    for (int i = 0; i < 3; ++i) NSA_CHECK_ARG(P.ns[i] >= 1 && P.ns[i] <= 16 && (P.ns[i] == 1 ? P.O[i] != nullptr : P.part[i] != nullptr), "decode_finish: bad branch input");
+    const dim3 grid((unsigned)((P.R * P.h + 3) / 4)), block(256);
+    if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(decode_finish_kernel<__bf16>, grid, block, 0, st, P);
+    else if (dtype == NSA_DT_F16) hipLaunchKernelGGL(decode_finish_kernel<_Float16>, grid, block, 0, st, P);
+    else hipLaunchKernelGGL(decode_finish_kernel<float>, grid, block, 0, st, P);
+    NSA_LAUNCH_CHECK("decode_finish");
+    return NSA_OK;
 }
 
 int launch_gate_combine(const GateCombineParams &P, int dtype, hipStream_t st) {

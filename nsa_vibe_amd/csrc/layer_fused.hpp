@@ -27,6 +27,20 @@ struct GateCombineParams {
     int h, Dk, Dv, Hd;
     float tau;
 };
+struct DecodeFinishParams {
+    const void *Q;
+    const float *part[3];  // cmp, sel, win: split-KV partial records (ns > 1) ...
+    const void *O[3];      // ... or the final branch output (ns == 1)
+    int ns[3];
+    void *O_out;
+    float *gates_out;
+    const void *w1, *b1, *w2, *b2;
+    int64_t R;
+    int h, Dk, Dv, Hd;
+    float tau;
+};
+int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st);
+int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st);
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
 int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st);
 int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st);

@@ -9,6 +9,7 @@
 
 #include "nsa_common.hpp"
 #include "sel_attn_params.hpp"
+#include "nsa_internal.hpp"
 
 namespace nsa {
 
@@ -83,10 +84,13 @@ size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, in
     return sel_attn_mfma_workspace((int64_t)B * S * G, h, Dv, nullptr);
 }
 
-int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, float *lse, int B,
-                     int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg,
-                     int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, int variant,
-                     void *workspace, size_t workspace_bytes, void *stream) {
+}  // extern "C"
+
+int nsa::sel_attn_fwd_impl(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, float *lse, int B, int S, int G,
+                           int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg,
+                           int64_t vss, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream,
+                           int defer, int *ns_used) {
+    if (ns_used) *ns_used = 1;
     NSA_CHECK_ARG(dtype_ok(dtype), "sel_attn_fwd: unknown dtype %d", dtype);
     NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0 && n_ranges >= 0,
                   "sel_attn_fwd: negative size");
@@ -123,10 +127,23 @@ int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t 
         if (ns > 1 && workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0)) {
             P.part = (float *)workspace;
             P.nsplit = ns;
+            P.defer_combine = defer;
+            if (ns_used && defer) *ns_used = ns;
         }
         return launch_sel_attn_fwd_mfma(P, dtype, st);
     }
     return launch_sel_attn_fwd_generic(P, dtype, st);
+}
+
+
+extern "C" {
+
+int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, float *lse, int B,
+                     int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg,
+                     int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, int variant,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+    return sel_attn_fwd_impl(Q, K, V, ranges, O, lse, B, S, G, h, Dk, Dv, S_kv, n_ranges, ksb, ksg, kss, vsb, vsg, vss, dtype, scale, variant,
+                             workspace, workspace_bytes, stream, 0, nullptr);
 }
 
 size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant) {
@@ -179,10 +196,13 @@ size_t nsa_band_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, i
     return band_attn_workspace(B, S, G, h, Dk, Dv, dtype, nullptr);
 }
 
-int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk,
-                      int Dv, int S_kv, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int t0,
-                      int a, int dd, int c, int w, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes,
-                      void *stream) {
+}  // extern "C"
+
+int nsa::band_attn_fwd_impl(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk, int Dv,
+                            int S_kv, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int t0, int a, int dd,
+                            int c, int w, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream,
+                            int defer, int *ns_used) {
+    if (ns_used) *ns_used = 1;
     NSA_CHECK_ARG(dtype_ok(dtype), "band_attn_fwd: unknown dtype %d", dtype);
     NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0, "band_attn_fwd: negative size");
     NSA_CHECK_ARG(t0 >= 0 && dd >= 1 && w >= 0, "band_attn_fwd: need t0 >= 0, dd >= 1, w >= 0");
@@ -209,10 +229,23 @@ int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void *O, floa
         if (ns > 1 && workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0)) {
             P.part = (float *)workspace;
             P.nsplit = ns;
+            P.defer_combine = defer;
+            if (ns_used && defer) *ns_used = ns;
         }
         return launch_band_attn_fwd_mfma(P, dtype, st);
     }
     return launch_band_attn_fwd_generic(P, dtype, st);
+}
+
+
+extern "C" {
+
+int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk,
+                      int Dv, int S_kv, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int t0,
+                      int a, int dd, int c, int w, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    return band_attn_fwd_impl(Q, K, V, O, lse, B, S, G, h, Dk, Dv, S_kv, ksb, ksg, kss, vsb, vsg, vss, t0, a, dd, c, w, dtype, scale, variant,
+                              workspace, workspace_bytes, stream, 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------ block meta (host)
@@ -375,11 +408,13 @@ size_t nsa_sel_decode_step_workspace(int B, int G, int h, int Dk, int Dv, int S_
     return a + p + c;
 }
 
-int nsa_sel_decode_step(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr,
-                        const int32_t *csc_rows, const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h, int Dk,
-                        int Dv, int S_cmp, int S_sel, int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb,
-                        int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
-                        int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream) {
+}  // extern "C"
+
+int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr, const int32_t *csc_rows,
+                              const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h, int Dk, int Dv, int S_cmp, int S_sel,
+                              int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb,
+                              int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *workspace,
+                              size_t workspace_bytes, void *stream, int defer, int *ns_used, float **part_used) {
     NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 16 == 0) &&
                       workspace_bytes >= nsa_sel_decode_step_workspace(B, G, h, Dk, Dv, S_cmp, S_sel, n_top, dtype),
                   "decode_step: workspace missing, misaligned or too small");
@@ -394,8 +429,22 @@ int nsa_sel_decode_step(const void *Q, const void *K_cmp, const void *K, const v
     rc = nsa_select_topn_ranges(p_grp, (int64_t)B * G, 1, G, t_token, nullptr, S_sel, l_sel, n_top, 1, 2, NSA_SEL_SEQUENTIAL, 1,
                                 ranges_out, n_top, stream);
     if (rc) return rc;
-    return nsa_sel_attn_fwd(Q, K, V, ranges_out, O, nullptr, B, 1, G, h, Dk, Dv, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, dtype,
-                            scale, 0, w + a + p, workspace_bytes - a - p, stream);
+    if (part_used) *part_used = (float *)(w + a + p);
+    return sel_attn_fwd_impl(Q, K, V, ranges_out, O, nullptr, B, 1, G, h, Dk, Dv, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, dtype, scale, 0,
+                             w + a + p, workspace_bytes - a - p, stream, defer, ns_used);
+}
+
+
+extern "C" {
+
+int nsa_sel_decode_step(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr,
+                        const int32_t *csc_rows, const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h, int Dk,
+                        int Dv, int S_cmp, int S_sel, int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb,
+                        int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
+                        int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream) {
+    return sel_decode_step_impl(Q, K_cmp, K, V, csc_ptr, csc_rows, csc_vals, ranges_out, O, B, G, h, Dk, Dv, S_cmp, S_sel, S_kv, l, d, l_sel,
+                                n_top, t_token, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg, vss, dtype, scale, workspace, workspace_bytes, stream, 0,
+                                nullptr, nullptr);
 }
 
 int nsa_indices_to_ranges_v2(const int32_t *indices, int64_t R, int S, int G, int t0, int K, int S_sel, int l_sel,

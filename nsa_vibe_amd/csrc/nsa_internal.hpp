@@ -1,0 +1,21 @@
+// Internal forms of a few C-ABI entry points: same arguments plus the split-KV hand-over used by the fused decode step
+// (defer != 0: the partial records stay in the workspace, *ns_used tells how many splits were written; 1 = O is final).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nsa {
+
+int sel_attn_fwd_impl(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, float *lse, int B, int S, int G, int h,
+                      int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
+                      int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream, int defer, int *ns_used);
+int band_attn_fwd_impl(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk, int Dv, int S_kv,
+                       int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int t0, int a, int dd, int c, int w,
+                       int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream, int defer, int *ns_used);
+int sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr, const int32_t *csc_rows,
+                         const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h, int Dk, int Dv, int S_cmp, int S_sel,
+                         int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb,
+                         int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *workspace,
+                         size_t workspace_bytes, void *stream, int defer, int *ns_used, float **part_used);
+
+}  // namespace nsa

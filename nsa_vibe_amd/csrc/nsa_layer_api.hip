@@ -3,6 +3,8 @@
 
 #include "nsa_common.hpp"
 #include "layer_fused.hpp"
+#include "nsa_internal.hpp"
+#include "sel_attn_params.hpp"
 
 using namespace nsa;
 
@@ -82,7 +84,7 @@ int nsa_gate_combine(const nsa_layer_desc *L, const void *Q, const void *O_cmp, 
 
 // workspace: proj | Q | O_cmp | O_sel | O_win | O_mix | ranges | selection-decode scratch | band scratch
 struct DecodeWs {
-    size_t proj, q, ocmp, osel, owin, omix, ranges, sel, band, total, sel_bytes, band_bytes;
+    size_t proj, q, ocmp, osel, owin, omix, ranges, sel, band, band2, total, sel_bytes, band_bytes;
 };
 static DecodeWs decode_ws(const nsa_layer_desc *L, int B, int S_max) {
     DecodeWs w;
@@ -103,6 +105,7 @@ static DecodeWs decode_ws(const nsa_layer_desc *L, int B, int S_max) {
     w.sel = o; o += up256(w.sel_bytes);
     w.band_bytes = nsa_band_attn_fwd_workspace(B, 1, L->G, L->h, L->Dk, L->Dv, L->dtype);
     w.band = o; o += up256(w.band_bytes);
+    w.band2 = o; o += up256(w.band_bytes);
     w.total = o;
     return w;
 }
@@ -132,34 +135,79 @@ int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const 
     void *proj = ws + W.proj, *Q = ws + W.q, *Ocmp = ws + W.ocmp, *Osel = ws + W.osel, *Owin = ws + W.owin, *Omix = ws + W.omix;
     int32_t *ranges = ranges_out ? ranges_out : (int32_t *)(ws + W.ranges);
 
-    // 1. fused QKV projection, 2. RoPE + cache append at position t
-    if (int rc = launch_linear_small(x, L->W_qkv, proj, B, NT, L->dim, dt, st)) return rc;
-    if (int rc = nsa_rope_cache_append(L, kv, proj, Q, 1, t, stream)) return rc;
+    RopeAppendParams RP{};
+    RP.proj = proj;
+    RP.Q_out = Q;
+    RP.cache[0] = kv->K_sel; RP.cache[1] = kv->V_sel; RP.cache[2] = kv->K_win; RP.cache[3] = kv->V_win; RP.cache[4] = kv->K_raw; RP.cache[5] = kv->V_raw;
+    RP.B = B; RP.S = 1; RP.G = G; RP.h = h; RP.Dk = Dk; RP.Dv = Dv; RP.S_max = kv->S_max; RP.t0 = t;
+    RP.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
+    RP.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    // 1+2. fused QKV projection with RoPE + cache append at position t in its epilogue
+    if (int rc = launch_qkv_rope_append(RP, x, L->W_qkv, L->dim, dt, st)) return rc;
     // 3. emit a compressed token when a window completes (nsa_attention.py:588-604)
     const int S_raw = t + 1;
     const int n_cmp = S_raw < L->l ? 0 : (S_raw - L->l) / L->d + 1;
+    NSA_CHECK_ARG(n_cmp <= kv->n_cmp_max, "layer_decode_step: compressed cache too small");
     if (S_raw >= L->l && (S_raw - L->l) % L->d == 0)
         if (int rc = nsa_cmp_pool_append(L, kv, n_cmp - 1, n_cmp, stream)) return rc;
-    NSA_CHECK_ARG(n_cmp <= kv->n_cmp_max, "layer_decode_step: compressed cache too small");
-    // 4. selected branch
     const int64_t ksb = (int64_t)G * kv->S_max * Dk, ksg = (int64_t)kv->S_max * Dk;
     const int64_t vsb = (int64_t)G * kv->S_max * Dv, vsg = (int64_t)kv->S_max * Dv;
     const int64_t kcb = (int64_t)G * kv->n_cmp_max * Dk, kcg = (int64_t)kv->n_cmp_max * Dk;
     const int64_t vcb = (int64_t)G * kv->n_cmp_max * Dv, vcg = (int64_t)kv->n_cmp_max * Dv;
     const float scale = 1.0f / sqrtf((float)Dk);
-    if (int rc = nsa_sel_decode_step(Q, kv->K_cmp, kv->K_sel, kv->V_sel, csc_ptr, csc_rows, csc_vals, ranges, Osel, B, G, h, Dk, Dv, n_cmp,
-                                     S_sel, S_raw, L->l, L->d, L->l_sel, L->n_sel, t, kcb, kcg, Dk, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale,
-                                     ws + W.sel, W.sel_bytes, stream))
+    // When the final pass can take split-KV partial records (Dv = 64) the three branches skip their own combine kernels:
+    // one kernel then merges the splits of all branches, evaluates the gate and mixes.
+    const int defer = Dv == 64 ? 1 : 0;
+    DecodeFinishParams F{};
+    F.Q = Q; F.O_out = Omix; F.gates_out = gates_out;
+    F.w1 = L->gate_w1; F.b1 = L->gate_b1; F.w2 = L->gate_w2; F.b2 = L->gate_b2;
+    F.R = (int64_t)B * G; F.h = h; F.Dk = Dk; F.Dv = Dv; F.Hd = L->gate_hidden; F.tau = L->gate_tau;
+    F.O[0] = Ocmp; F.O[1] = Osel; F.O[2] = Owin;
+    // 4. selected branch
+    float *sel_part = nullptr;
+    if (int rc = sel_decode_step_impl(Q, kv->K_cmp, kv->K_sel, kv->V_sel, csc_ptr, csc_rows, csc_vals, ranges, Osel, B, G, h, Dk, Dv, n_cmp,
+                                      S_sel, S_raw, L->l, L->d, L->l_sel, L->n_sel, t, kcb, kcg, Dk, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale,
+                                      ws + W.sel, W.sel_bytes, stream, defer, &F.ns[1], &sel_part))
         return rc;
-    // 5. sliding and compressed branches
-    if (int rc = nsa_band_attn_fwd(Q, kv->K_win, kv->V_win, Owin, nullptr, B, 1, G, h, Dk, Dv, S_raw, ksb, ksg, Dk, vsb, vsg, Dv, t, 0, 1, 0,
-                                   L->w, dt, scale, 0, ws + W.band, W.band_bytes, stream))
-        return rc;
-    if (int rc = nsa_band_attn_fwd(Q, kv->K_cmp, kv->V_cmp, Ocmp, nullptr, B, 1, G, h, Dk, Dv, n_cmp, kcb, kcg, Dk, vcb, vcg, Dv, t, L->l, L->d,
-                                   1, 1 << 30, dt, scale, 0, ws + W.band, W.band_bytes, stream))
-        return rc;
-    // 6. gates + combine, 7. output projection
-    if (int rc = nsa_gate_combine(L, Q, Ocmp, Osel, Owin, Omix, gates_out, (int64_t)B * G, stream)) return rc;
+    F.part[1] = sel_part;
+    // 5. sliding and compressed branches: one launch when both run in split-KV form
+    int ns_band = 1;
+    band_attn_workspace(B, 1, G, h, Dk, Dv, dt, &ns_band);
+    const bool dual = defer && ns_band > 1 && n_cmp > 0 && L->w > 0 && band_attn_mfma_supported(dt, h, Dk, Dv) &&
+                      ((uintptr_t)kv->K_win % 16 == 0) && ((uintptr_t)kv->V_win % 16 == 0) && ((uintptr_t)kv->K_cmp % 16 == 0) &&
+                      ((uintptr_t)kv->V_cmp % 16 == 0) && ksb * 2 < ((int64_t)1 << 31) && vsb * 2 < ((int64_t)1 << 31);
+    if (dual) {
+        BandAttnParams PW{}, PC{};
+        PW.Q = Q; PW.K = kv->K_win; PW.V = kv->V_win; PW.O = Owin;
+        PW.B = B; PW.S = 1; PW.G = G; PW.h = h; PW.Dk = Dk; PW.Dv = Dv; PW.S_kv = S_raw;
+        PW.ksb = ksb; PW.ksg = ksg; PW.kss = Dk; PW.vsb = vsb; PW.vsg = vsg; PW.vss = Dv;
+        PW.scale = scale; PW.t0 = t; PW.a = 0; PW.dd = 1; PW.c = 0; PW.w = L->w;
+        PW.part = (float *)(ws + W.band); PW.nsplit = ns_band; PW.defer_combine = 1;
+        PC = PW;
+        PC.K = kv->K_cmp; PC.V = kv->V_cmp; PC.O = Ocmp; PC.S_kv = n_cmp;
+        PC.ksb = kcb; PC.ksg = kcg; PC.vsb = vcb; PC.vsg = vcg;
+        PC.a = L->l; PC.dd = L->d; PC.c = 1; PC.w = 1 << 30;
+        PC.part = (float *)(ws + W.band2);
+        if (int rc = launch_band_attn_fwd_dual(PW, PC, dt, st)) return rc;
+        F.ns[2] = F.ns[0] = ns_band;
+        F.part[2] = PW.part;
+        F.part[0] = PC.part;
+    } else {
+        if (int rc = band_attn_fwd_impl(Q, kv->K_win, kv->V_win, Owin, nullptr, B, 1, G, h, Dk, Dv, S_raw, ksb, ksg, Dk, vsb, vsg, Dv, t, 0, 1, 0,
+                                        L->w, dt, scale, 0, ws + W.band, W.band_bytes, stream, defer, &F.ns[2]))
+            return rc;
+        F.part[2] = (const float *)(ws + W.band);
+        if (int rc = band_attn_fwd_impl(Q, kv->K_cmp, kv->V_cmp, Ocmp, nullptr, B, 1, G, h, Dk, Dv, n_cmp, kcb, kcg, Dk, vcb, vcg, Dv, t, L->l,
+                                        L->d, 1, 1 << 30, dt, scale, 0, ws + W.band2, W.band_bytes, stream, defer, &F.ns[0]))
+            return rc;
+        F.part[0] = (const float *)(ws + W.band2);
+    }
+    // 6. split combine + gates + mix, 7. output projection
+    if (defer) {
+        if (int rc = launch_decode_finish(F, dt, st)) return rc;
+    } else {
+        if (int rc = nsa_gate_combine(L, Q, Ocmp, Osel, Owin, Omix, gates_out, (int64_t)B * G, stream)) return rc;
+    }
     return launch_linear_small(Omix, L->W_out, y, B, L->dim, NO, dt, st);
 }
 

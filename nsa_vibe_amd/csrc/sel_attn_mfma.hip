@@ -418,7 +418,7 @@ static int launch_mfma_t(const SelAttnParams &P0, hipStream_t st) {
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, P);
     NSA_LAUNCH_CHECK("sel_attn_fwd_mfma");
-    if (split) {
+    if (split && !P.defer_combine) {
         hipLaunchKernelGGL((sel_attn_combine_kernel<T, D>), dim3((unsigned)((P.R * P.h + 3) / 4)), dim3(256), 0, st, P);
         NSA_LAUNCH_CHECK("sel_attn_combine");
     }

@@ -20,6 +20,7 @@ struct SelAttnParams {
     float *part;  // workspace or null
     int nsplit;
     int map_mode;  // 0 rows linear in blockIdx; 1 workgroup = 4 tokens of one (b,g); 2 = 1 + XCD-aware order
+    int defer_combine;  // split-KV: leave the partial records for the caller's own combine pass
 };
 
 struct SelAttnBwdParams {
@@ -53,6 +54,7 @@ struct BandAttnParams {
     int nsplit;
     int map_mode;  // 0 linear, 1 workgroup = 4 token groups of one (b,g), 2 = 1 + XCD-aware order
     int tpw;       // tokens per wave
+    int defer_combine;  // split-KV: leave the partial records for the caller's own combine pass
 };
 __host__ __device__ inline int band_hi(int t0, int a, int dd, int c, int S_kv, int t) {
     const int e = t0 + t + 1 - a;
@@ -63,6 +65,7 @@ __host__ __device__ inline int band_hi(int t0, int a, int dd, int c, int S_kv, i
 bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
 size_t band_attn_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int *nsplit_out);
 int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st);
+int launch_band_attn_fwd_dual(const BandAttnParams &P0, const BandAttnParams &P1, int dtype, hipStream_t st);
 int launch_band_attn_fwd_generic(const BandAttnParams &P, int dtype, hipStream_t st);
 
 int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);

@@ -21,14 +21,15 @@ dev = torch.device("cuda")
 m = nv.NSAAttention(768, 12, 2, 64, 64, 32, 16, 64, 16, 512, selector="batched").to(dev).to(torch.bfloat16).eval()
 x = torch.randn(B, S, 768, device=dev, dtype=torch.bfloat16)
 with torch.no_grad():
-    for it in range(3):
+    best = 1e9
+    for it in range(6):
         kv = m.new_kv(B, S + steps + 8, dev, torch.bfloat16)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         y, kv = m(x, kv, prefill=True)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-    print(f"prefill S={S} B={B}: {1e3 * (t1 - t0):.3f} ms  ({B * S / (t1 - t0) / 1e6:.2f} M tok/s)")
+        best = min(best, time.perf_counter() - t0)
+    print(f"prefill S={S} B={B}: {1e3 * best:.3f} ms  ({B * S / best / 1e6:.2f} M tok/s)  [best of 6]")
     xt = torch.randn(B, 1, 768, device=dev, dtype=torch.bfloat16)
     for _ in range(8):
         y, kv = m(xt, kv, prefill=False)
