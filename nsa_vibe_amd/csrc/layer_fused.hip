@@ -274,19 +274,39 @@ __device__ __forceinline__ void gate_probs(const T *Qr, int h, int Dk, int Hd, c
         sqp[dk] = rnd<T>(a / (float)h);
     }
     wave_lds_fence();
-    float act = 0.f;
-    if (lane < Hd) {
-        const T *w1 = (const T *)w1_ + (int64_t)lane * Dk;
-        float a = 0.f;
-        for (int dk = 0; dk < Dk; ++dk) a = fmaf(Elt<T>::to_f(w1[dk]), sqp[dk], a);
-        a = rnd<T>(a + Elt<T>::to_f(((const T *)b1_)[lane]));
-        act = rnd<T>(a / (1.f + expf(-a)));  // silu
+    // fc1 + silu + fc2: hidden unit j = j0 + lane % 32, the two half-waves split the Dk axis of its dot product (16-byte
+    // weight loads); the fc2 contributions of the units are summed over the lanes at the end
+    float g3[3] = {0.f, 0.f, 0.f};
+    {
+        const int half = lane >> 5, dspan = (Dk + 1) >> 1, d0 = half * dspan, d1 = min(Dk, d0 + dspan);
+        const bool vec = (dspan % 8 == 0) && ((uintptr_t)w1_ % 16 == 0);
+        for (int j0 = 0; j0 < Hd; j0 += 32) {
+            const int j = j0 + (lane & 31);
+            float a = 0.f;
+            if (j < Hd) {
+                const T *w1 = (const T *)w1_ + (int64_t)j * Dk;
+                for (int dk = d0; dk < d1; dk += 8) {
+                    float wv[8];
+                    load8<T>(w1 + dk, d1 - dk, vec, wv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (dk + e < d1) a = fmaf(wv[e], sqp[dk + e], a);
+                }
+            }
+            const float other = __shfl_xor(a, 32, 64);
+            a = half == 0 ? a + other : other + a;  // low half + high half on both lanes
+            if (j < Hd && half == 0) {
+                a = rnd<T>(a + Elt<T>::to_f(((const T *)b1_)[j]));
+                const float act = rnd<T>(a / (1.f + expf(-a)));  // silu
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g3[k] = fmaf(Elt<T>::to_f(((const T *)w2_)[k * Hd + j]), act, g3[k]);
+            }
+        }
     }
     float gl[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float part = lane < Hd ? Elt<T>::to_f(((const T *)w2_)[k * Hd + lane]) * act : 0.f;
-        gl[k] = rnd<T>(wave_sum(part) + Elt<T>::to_f(((const T *)b2_)[k]));
+        gl[k] = rnd<T>(wave_sum(g3[k]) + Elt<T>::to_f(((const T *)b2_)[k]));
         gl[k] = rnd<T>(gl[k] / fmaxf(tau, 1e-6f));
     }
     const float mx = fmaxf(gl[0], fmaxf(gl[1], gl[2]));
@@ -308,6 +328,70 @@ __device__ __forceinline__ void gate_probs(const T *Qr, int h, int Dk, int Hd, c
     for (int k = 0; k < 3; ++k) pr[k] = peaked ? (k == arg ? 1.f : 0.f) : rnd<T>(pr[k] / den);
 }
 
+// The m7c geometry (Dk = 64, hidden <= 32, h <= 8) with every global load issued up front and no data-dependent branch
+// before the arithmetic: in decode this kernel is a handful of waves and its time is the length of its load -> use chains.
+// Same arithmetic, same rounding points as gate_probs.
+template <typename T>
+struct GateFast {
+    float qv[8], w1v[4][8], b1v, w2v[3], b2v[3];
+    __device__ __forceinline__ void load(const T *Qr, int h, int Hd, const void *w1_, const void *b1_, const void *w2_, const void *b2_) {
+        const int lane = lane_id(), j = min(lane & 31, Hd - 1), half = lane >> 5;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) qv[hh] = Elt<T>::to_f(Qr[min(hh, h - 1) * 64 + lane]);
+        const T *w1 = (const T *)w1_ + (int64_t)j * 64 + 32 * half;
+        const bool vec = ((uintptr_t)w1_ % 16) == 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) load8<T>(w1 + 8 * c, 8, vec, w1v[c]);
+        b1v = Elt<T>::to_f(((const T *)b1_)[j]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            w2v[k] = Elt<T>::to_f(((const T *)w2_)[k * Hd + j]);
+            b2v[k] = Elt<T>::to_f(((const T *)b2_)[k]);
+        }
+    }
+    __device__ __forceinline__ void compute(int h, int Hd, float tau, float *sqp, float (&pr)[3]) const {
+        const int lane = lane_id(), half = lane >> 5;
+        float a = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) a += hh < h ? qv[hh] : 0.f;
+        sqp[lane] = rnd<T>(a / (float)h);
+        wave_lds_fence();
+        a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(w1v[c][e], sqp[32 * half + 8 * c + e], a);
+        const float other = __shfl_xor(a, 32, 64);
+        a = half == 0 ? a + other : other + a;
+        a = rnd<T>(a + b1v);
+        const float act = rnd<T>(a / (1.f + expf(-a)));
+        const bool mine = half == 0 && (lane & 31) < Hd;
+        float gl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gl[k] = rnd<T>(wave_sum(mine ? w2v[k] * act : 0.f) + b2v[k]);
+            gl[k] = rnd<T>(gl[k] / fmaxf(tau, 1e-6f));
+        }
+        const float mx = fmaxf(gl[0], fmaxf(gl[1], gl[2]));
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pr[k] = expf(gl[k] - mx);
+            den += pr[k];
+        }
+        int arg = 0;
+        if (gl[1] > gl[arg]) arg = 1;
+        if (gl[2] > gl[arg]) arg = 2;
+        float second = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k != arg) second = fmaxf(second, gl[k]);
+        const bool peaked = (gl[arg] - second) > 50.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pr[k] = peaked ? (k == arg ? 1.f : 0.f) : rnd<T>(pr[k] / den);
+    }
+};
+
 template <typename T>
 __device__ __forceinline__ float mix3(const float (&pr)[3], float oc, float os, float ow) {
     const float t1 = rnd<T>(pr[0] * oc), t2 = rnd<T>(pr[1] * os);
@@ -322,7 +406,13 @@ __global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) 
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= P.R) return;
     float pr[3];
-    gate_probs<T>((const T *)P.Q + row * P.h * P.Dk, P.h, P.Dk, P.Hd, P.w1, P.b1, P.w2, P.b2, P.tau, sqp[wave], pr);
+    if (P.Dk == 64 && P.Hd <= 32 && P.h <= 8) {
+        GateFast<T> gf;
+        gf.load((const T *)P.Q + row * P.h * 64, P.h, P.Hd, P.w1, P.b1, P.w2, P.b2);
+        gf.compute(P.h, P.Hd, P.tau, sqp[wave], pr);
+    } else {
+        gate_probs<T>((const T *)P.Q + row * P.h * P.Dk, P.h, P.Dk, P.Hd, P.w1, P.b1, P.w2, P.b2, P.tau, sqp[wave], pr);
+    }
     if (P.gates_out && lane < 3) P.gates_out[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
     const int64_t base = row * P.h * P.Dv;
     const T *Oc = (const T *)P.O_cmp + base, *Os = (const T *)P.O_sel + base, *Ow = (const T *)P.O_win + base;
@@ -342,32 +432,40 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeFinishParams P
     const int64_t row = wid / P.h;
     const int hh = (int)(wid - row * P.h);
     constexpr int D = 64;
-    float o[3];
+    const T *Qr = (const T *)P.Q + row * P.h * P.Dk;
+    const bool fast = P.Dk == 64 && P.Hd <= 32 && P.h <= 8;
+    // ---- every load first (split indices are clamped instead of predicated: a clamped duplicate gets weight 0 below)
+    GateFast<T> gf;
+    if (fast) gf.load(Qr, P.h, P.Hd, P.w1, P.b1, P.w2, P.b2);
+    float mv[3], lv[3], pv[3][16], fin[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int ns = P.ns[i];
-        if (ns <= 1) {
-            o[i] = Elt<T>::to_f(((const T *)P.O[i])[wid * D + lane]);
-            continue;
-        }
-        const float *base = P.part[i] + ((row * ns) * (int64_t)P.h + hh) * (D + PART_PAD);
+        const bool split = ns > 1;
+        const float *base = split ? P.part[i] + ((row * ns) * (int64_t)P.h + hh) * (D + PART_PAD) : (const float *)nullptr;
         const int64_t sstride = (int64_t)P.h * (D + PART_PAD);
-        float m = -INFINITY, l = 0.f;
-        if (lane < ns) {
-            m = base[lane * sstride];
-            l = base[lane * sstride + 1];
-        }
-        const float mmax = wave_max(m);
-        const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mmax);
-        const float ltot = wave_sum(l * w);
+        fin[i] = split ? 0.f : Elt<T>::to_f(((const T *)P.O[i])[wid * D + lane]);
+        mv[i] = (split && lane < ns) ? base[lane * sstride] : -INFINITY;
+        lv[i] = (split && lane < ns) ? base[lane * sstride + 1] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pv[i][s] = split ? base[min(s, ns - 1) * sstride + PART_PAD + lane] : 0.f;
+    }
+    // ---- arithmetic
+    float pr[3];
+    if (fast) gf.compute(P.h, P.Hd, P.tau, sqp[wave], pr);
+    else gate_probs<T>(Qr, P.h, P.Dk, P.Hd, P.w1, P.b1, P.w2, P.b2, P.tau, sqp[wave], pr);
+    float o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float mmax = wave_max(mv[i]);
+        const float w = (mv[i] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mv[i] - mmax);  // lanes >= ns: 0
+        const float ltot = wave_sum(lv[i] * w);
         float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            if (s < ns) acc = fmaf(base[s * sstride + PART_PAD + lane], __shfl(w, s, 64), acc);
-        o[i] = rnd<T>(acc * (ltot > 0.f ? 1.f / ltot : 0.f));  // the branch output in the activation dtype, as its own combine pass leaves it
+        for (int s = 0; s < 16; ++s) acc = fmaf(pv[i][s], __shfl(w, s, 64), acc);
+        // the branch output in the activation dtype, as its own combine pass leaves it
+        o[i] = P.ns[i] > 1 ? rnd<T>(acc * (ltot > 0.f ? 1.f / ltot : 0.f)) : fin[i];
     }
-    float pr[3];
-    gate_probs<T>((const T *)P.Q + row * P.h * P.Dk, P.h, P.Dk, P.Hd, P.w1, P.b1, P.w2, P.b2, P.tau, sqp[wave], pr);
     if (P.gates_out && hh == 0 && lane < 3) P.gates_out[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
     ((T *)P.O_out)[wid * D + lane] = Elt<T>::from_f(mix3<T>(pr, o[0], o[1], o[2]));
 }

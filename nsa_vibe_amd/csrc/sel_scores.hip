@@ -286,30 +286,84 @@ __global__ __launch_bounds__(64) void decode_pgrp_kernel(DecodeParams P) {
     const int64_t row = blockIdx.y;
     const int lane = threadIdx.x;
     const int nchunk = dec_nchunk(P.S_cmp);
-    for (int hh = 0; hh < P.h; ++hh) {  // h <= 64
-        const float *pr = P.part + (row * P.h + hh) * (int64_t)nchunk * 2;
-        float m = -INFINITY;
-        for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, pr[2 * c]);
-        m = wave_max(m);
-        float l = 0.f;
-        for (int c = lane; c < nchunk; c += 64) l += pr[2 * c + 1] * __builtin_amdgcn_exp2f(pr[2 * c] - m);
-        l = wave_sum(l);
-        if (lane == 0) mlog_s[hh] = m + __builtin_amdgcn_logf(l);
+    // per-head softmax statistics from the chunk records.  The kernel is latency bound (a handful of waves per decode
+    // step): the loads of 8 heads are issued together, the arithmetic per head is unchanged.
+    for (int h0 = 0; h0 < P.h; h0 += 8) {
+        if (nchunk <= 64) {
+            float mv[8], lv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = h0 + i < P.h && lane < nchunk;
+                const float *pr = P.part + (row * P.h + min(h0 + i, P.h - 1)) * (int64_t)nchunk * 2;
+                mv[i] = ok ? pr[2 * lane] : -INFINITY;
+                lv[i] = ok ? pr[2 * lane + 1] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (h0 + i >= P.h) break;
+                const float m = wave_max(mv[i]);
+                const float l = wave_sum(lane < nchunk ? lv[i] * __builtin_amdgcn_exp2f(mv[i] - m) : 0.f);
+                if (lane == 0) mlog_s[h0 + i] = m + __builtin_amdgcn_logf(l);
+            }
+        } else {
+            for (int hh = h0; hh < min(P.h, h0 + 8); ++hh) {
+                const float *pr = P.part + (row * P.h + hh) * (int64_t)nchunk * 2;
+                float m = -INFINITY;
+                for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, pr[2 * c]);
+                m = wave_max(m);
+                float l = 0.f;
+                for (int c = lane; c < nchunk; c += 64) l += pr[2 * c + 1] * __builtin_amdgcn_exp2f(pr[2 * c] - m);
+                l = wave_sum(l);
+                if (lane == 0) mlog_s[hh] = m + __builtin_amdgcn_logf(l);
+            }
+        }
     }
     wave_lds_fence();
     const int j = blockIdx.x * 64 + lane;
     if (j >= P.S_sel) return;
     const int k0 = P.csc_ptr[j], k1 = P.csc_ptr[j + 1];
     float grp = 0.f;
-    for (int hh = 0; hh < P.h; ++hh) {
-        const float *x = P.x + (row * P.h + hh) * (int64_t)P.S_cmp;
-        const float ml = mlog_s[hh];
-        float acc = 0.f;
-        for (int k = k0; k < k1; ++k) {
-            const int r = P.csc_rows[k];
-            if (r < P.S_cmp) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[r] - ml), P.csc_vals[k]));
+    if (k1 - k0 <= 8) {
+        // taps of this selection block (ascending cmp row), then the logits of 4 heads x 8 taps per round of loads
+        int rr[8];
+        float vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool ok = k0 + t < k1;
+            const int r = ok ? P.csc_rows[k0 + t] : P.S_cmp;
+            rr[t] = r < P.S_cmp ? r : -1;
+            vv[t] = ok ? P.csc_vals[k0 + t] : 0.f;
         }
-        grp = __fadd_rn(grp, acc);
+        for (int h0 = 0; h0 < P.h; h0 += 4) {
+            float xs[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float *x = P.x + (row * P.h + min(h0 + i, P.h - 1)) * (int64_t)P.S_cmp;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) xs[i][t] = rr[t] >= 0 ? x[rr[t]] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (h0 + i >= P.h) break;
+                const float ml = mlog_s[h0 + i];
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (rr[t] >= 0) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(xs[i][t] - ml), vv[t]));
+                grp = __fadd_rn(grp, acc);
+            }
+        }
+    } else {
+        for (int hh = 0; hh < P.h; ++hh) {
+            const float *x = P.x + (row * P.h + hh) * (int64_t)P.S_cmp;
+            const float ml = mlog_s[hh];
+            float acc = 0.f;
+            for (int k = k0; k < k1; ++k) {
+                const int r = P.csc_rows[k];
+                if (r < P.S_cmp) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[r] - ml), P.csc_vals[k]));
+            }
+            grp = __fadd_rn(grp, acc);
+        }
     }
     P.p_grp[row * (int64_t)P.S_sel + j] = grp;
 }

@@ -155,8 +155,8 @@ class NSAAttention(nn.Module):
         """(nsa_layer_desc, fused W_qkv) -- rebuilt when a parameter was modified or moved (tensor version counters)"""
         ps = [getattr(self, n).weight for n in self._QKV] + [self.out.weight, self.gate.fc1.weight, self.gate.fc1.bias,
                                                                self.gate.fc2.weight, self.gate.fc2.bias]
-        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
-        if getattr(self, "_desc_key", None) != key:
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_desc_key", None) != key or self._desc_keep[0].dtype != ps[0].dtype:
             W_qkv = torch.cat([p.detach() for p in ps[:7]], dim=0).contiguous()
             keep = [W_qkv] + [p.detach().contiguous() for p in ps[7:]]
             d = _lib.NsaLayerDesc()
@@ -274,8 +274,11 @@ class NSAAttention(nn.Module):
         cptr, crows, cvals = kv.meta.device_csc(dev)
         xc = x.reshape(B, self.dim).contiguous()
         y = torch.empty((B, 1, self.dim), dtype=x.dtype, device=dev)
-        ranges = torch.empty((B, self.n_kv_groups, self.n_sel, 2), dtype=torch.int32, device=dev)
-        gates = torch.empty((B, 1, self.n_kv_groups, 3), dtype=torch.float32, device=dev)
+        mon = getattr(kv, "_monitors", None)  # ranges / gates of the latest step (overwritten every step)
+        if mon is None:
+            mon = kv._monitors = (torch.empty((B, self.n_kv_groups, self.n_sel, 2), dtype=torch.int32, device=dev),
+                                  torch.empty((B, 1, self.n_kv_groups, 3), dtype=torch.float32, device=dev))
+        ranges, gates = mon
         rc = L.nsa_layer_decode_step(ctypes.byref(desc), ctypes.byref(kd), xc.data_ptr(), y.data_ptr(), t, cptr.data_ptr(),
                                      crows.data_ptr(), cvals.data_ptr(), int(kv.meta.S_sel), ranges.data_ptr(), gates.data_ptr(),
                                      wptr, ws.numel() - (wptr - ws.data_ptr()), _stream(dev))
