@@ -15,7 +15,8 @@ The JSON line also carries
                vs the 8 TB/s HBM peak (L_row*(Dk+Dv)*sizeof per (b,t,g) row)
   cpu_baseline the CPU oracle (a port of the reference path, validated against the reference) timed on
                this node's host cores on a bounded sample of the same workload
-  extra        decode tok/s and prefill ms at S in {4k,16k,64k}, MFMA TFLOP/s of the attention kernel
+  extra        decode tok/s and prefill ms at S in {4k,16k,64k} of the hot path, MFMA TFLOP/s of the attention kernel,
+               selection backward, the sliding/compressed branch kernel, and the whole NSAAttention layer (native path)
 """
 import argparse
 import json
@@ -93,6 +94,74 @@ def decode_bench(nv, B, S_ctx, steps, device):
 
     ms = time_events(step, steps, warm=3)
     return B / (ms * 1e-3), ms
+
+
+def band_bench(nv, B, S, device, iters=5):
+    """sliding-window (w=512) and compressed (l=32, d=16) branch kernels: ms and MFMA TFLOP/s (4*h*D flops per (row, key))"""
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    mk = lambda *sh: torch.randn(*sh, device=device, generator=g).bfloat16()  # noqa: E731
+    S_cmp = (S - L_CMP) // D_CMP + 1
+    Q, K, V, Kc, Vc = mk(B, S, G, H, D), mk(B, G, S, D), mk(B, G, S, D), mk(B, G, S_cmp, D), mk(B, G, S_cmp, D)
+    t = torch.arange(S)
+    keys_win = int(torch.clamp(t + 1, max=512).sum())
+    keys_cmp = int(torch.where(t + 1 < L_CMP, 0, (t + 1 - L_CMP) // D_CMP + 1).sum())
+    out = {}
+    for name, fn, keys in (("win", lambda: nv.sliding_window_attention(Q, K, V, 512), keys_win),
+                           ("cmp", lambda: nv.batched_causal_attention_compressed(Q, Kc, Vc, L_CMP, D_CMP), keys_cmp)):
+        ms = time_events(fn, iters)
+        out[name] = {"ms": ms, "tflops": 4.0 * B * G * H * D * keys / (ms * 1e-3) / 1e12}
+    return out
+
+
+def backward_bench(nv, meta, Q, K, V, S, iters=5):
+    """selection attention forward + backward (autograd through the HIP kernels) on the bench workload"""
+    B = Q.shape[0]
+    g = torch.Generator(device=Q.device)
+    g.manual_seed(6)
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device=Q.device, generator=g), meta, N_SEL, S)
+    dO = torch.randn(Q.shape, device=Q.device, generator=g).bfloat16()
+    q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    tf = tb = 0.0
+    a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    for i in range(iters + 2):
+        q.grad = k.grad = v.grad = None
+        a.record()
+        O = nv.selection_attention_hip(q, k, v, rg)
+        b.record()
+        O.backward(dO)
+        c.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            tf += a.elapsed_time(b) / iters
+            tb += b.elapsed_time(c) / iters
+    return {"fwd_ms": tf, "bwd_ms": tb}
+
+
+def layer_bench(nv, B, S, device, steps=40):
+    """the whole NSAAttention layer (cmp + sel + win branches, gate, projections) on the native path: prefill ms, decode tok/s"""
+    torch.manual_seed(0)
+    m = nv.NSAAttention(768, 12, G, D, D, L_CMP, D_CMP, L_SEL, N_SEL, 512, selector="batched").to(device).to(torch.bfloat16).eval()
+    x = torch.randn(B, S, 768, device=device, dtype=torch.bfloat16)
+    with torch.no_grad():
+        best = 1e9
+        for _ in range(4):
+            kv = m.new_kv(B, S + steps + 16, device, torch.bfloat16)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, kv = m(x, kv, prefill=True)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        xt = torch.randn(B, 1, 768, device=device, dtype=torch.bfloat16)
+        for _ in range(8):
+            _, kv = m(xt, kv, prefill=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, kv = m(xt, kv, prefill=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    return {"prefill_ms": best * 1e3, "prefill_tok_per_s": B * S / best, "decode_us_per_step": dt * 1e6, "decode_tok_per_s": B / dt}
 
 
 def cpu_baseline(S, B, seed=3, min_seconds=10.0):
@@ -230,6 +299,16 @@ def main():
                     extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "scores_ms": sc, "select_ms": se, "attention_ms": at,
                                                     "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9, "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12}
                     del m2, Q2, Kc2, K2, V2
+                # next scope rows: backward, the sliding/compressed branch kernel (MFMA bound), the whole layer on the native path
+                extra[f"sel_attn_fwd_bwd_S{S}_B{B}"] = backward_bench(nv, meta, Q, K, V, S)
+                for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
+                    extra[f"band_S{S2}_B{B2}"] = band_bench(nv, B2, S2, device)
+                bw = extra["band_S65536_B1"]["cmp"]
+                out["roofline_mfma"] = {"kernel": "band_attn_fwd_kernel<bf16,3> (compressed branch, S=65536)", "bound": "mfma",
+                                        "achieved": bw["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": bw["tflops"] / MFMA_BF16_PEAK_TFLOPS, "kernel_ms": bw["ms"]}
+                for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
+                    extra[f"layer_S{S2}_B{B2}"] = layer_bench(nv, B2, S2, device)
             except Exception as e:  # noqa: BLE001 -- extras must not void the headline number
                 extra["error"] = repr(e)
             out["extra"] = extra
