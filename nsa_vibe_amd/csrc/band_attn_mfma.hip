@@ -184,32 +184,41 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         if (tile + 1 < tile_end) issue_dma(tok0 + 32);
 
         const bool interior = tok0 >= lo_max && tok0 + 32 <= hi_min;  // every key valid for every slot
+        // S^T of all column tiles first, ONE slow-path decision per key tile: the common path below is straight-line code, so
+        // the softmax VALU work of one column tile is scheduled against the MFMAs of its neighbours
+        f32x4 sacc[NT][2];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            f32x4 sacc[2];
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                sacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sacc[n][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) sacc[u] = M::mma(kfr[u][s], qf[n][s], sacc[u]);
+                for (int s = 0; s < 2; ++s) sacc[n][u] = M::mma(kfr[u][s], qf[n][s], sacc[n][u]);
             }
-            // key of sacc[u][j] = tok0 + 16u + 4q + j
-            float x[8];
+        // key of sacc[n][u][j] = tok0 + 16u + 4q + j
+        float x[NT][8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[4 * u + j] = fmaf(sacc[u][j], c2, -mrun[n]);
-            const float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-            if (!interior || __any(!(tmax <= RESCALE_THR))) {
-                asm volatile("; slow path: masks and/or raise the running max" ::: "memory");
+                for (int j = 0; j < 4; ++j) x[n][4 * u + j] = fmaf(sacc[n][u][j], c2, -mrun[n]);
+            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(x[n][0], x[n][1]), fmaxf(x[n][2], x[n][3])),
+                                     fmaxf(fmaxf(x[n][4], x[n][5]), fmaxf(x[n][6], x[n][7]))));
+        }
+        if (!interior || __any(!(tmax <= RESCALE_THR))) {
+            asm volatile("; slow path: masks and/or raise the running max" ::: "memory");
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
                 float vmax = -INFINITY;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int key = tok0 + 16 * u + 4 * q + j;
-                        const float v = (key >= lo_s[n] && key < hi_s[n]) ? sacc[u][j] * c2 : -INFINITY;
-                        x[4 * u + j] = v;
+                        const float v = (key >= lo_s[n] && key < hi_s[n]) ? sacc[n][u][j] * c2 : -INFINITY;
+                        x[n][4 * u + j] = v;
                         vmax = fmaxf(vmax, v);
                     }
                 vmax = fmaxf(vmax, __shfl_xor(vmax, 16, 64));
@@ -222,13 +231,16 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
 #pragma unroll
                 for (int m = 0; m < 4; ++m) o[n][m] *= alpha;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] -= msub;
+                for (int j = 0; j < 8; ++j) x[n][j] -= msub;
             }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
             float psum = 0.f;
             x8 pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float pe = __builtin_amdgcn_exp2f(x[j]);
+                const float pe = __builtin_amdgcn_exp2f(x[n][j]);
                 psum += pe;
                 pf[j] = Elt<T>::from_f(pe);
             }
