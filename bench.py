@@ -164,6 +164,31 @@ def layer_bench(nv, B, S, device, steps=40):
     return {"prefill_ms": best * 1e3, "prefill_tok_per_s": B * S / best, "decode_us_per_step": dt * 1e6, "decode_tok_per_s": B / dt}
 
 
+def layer_train_bench(nv, B, S, device, iters=5):
+    """forward + backward of the NSAAttention layer with autograd (config 5 shape): the attention branches run the HIP
+    forward/backward kernels, projections / RoPE / gate are eager differentiable torch ops"""
+    torch.manual_seed(0)
+    m = nv.NSAAttention(768, 12, G, D, D, L_CMP, D_CMP, L_SEL, N_SEL, 512, selector="batched").to(device).to(torch.bfloat16).train()
+    x = torch.randn(B, S, 768, device=device, dtype=torch.bfloat16, requires_grad=True)
+    go = torch.randn(B, S, 768, device=device, dtype=torch.bfloat16)
+    a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    tf = tb = 0.0
+    for i in range(iters + 2):
+        m.zero_grad(set_to_none=True)
+        x.grad = None
+        kv = m.new_kv(B, S, device, torch.bfloat16)
+        a.record()
+        out, _ = m(x, kv, prefill=True)
+        b.record()
+        out.backward(go)
+        c.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            tf += a.elapsed_time(b) / iters
+            tb += b.elapsed_time(c) / iters
+    return {"fwd_ms": tf, "bwd_ms": tb, "tok_per_s": B * S / ((tf + tb) * 1e-3)}
+
+
 def cpu_baseline(S, B, seed=3, min_seconds=10.0):
     """The oracle (CPU restatement of the reference path, fp32) on the same workload, repeated over the batch
     until ~10 s of host time have been spent (bounded sample)."""
@@ -309,6 +334,7 @@ def main():
                                         "frac": bw["tflops"] / MFMA_BF16_PEAK_TFLOPS, "kernel_ms": bw["ms"]}
                 for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
                     extra[f"layer_S{S2}_B{B2}"] = layer_bench(nv, B2, S2, device)
+                extra[f"layer_train_S{S}_B{B}"] = layer_train_bench(nv, B, S, device)
             except Exception as e:  # noqa: BLE001 -- extras must not void the headline number
                 extra["error"] = repr(e)
             out["extra"] = extra
