@@ -89,7 +89,7 @@ static int linear_small_t(const void *A, const void *W, void *out, int M, int N,
     NSA_LAUNCH_CHECK("linear_small");
     return NSA_OK;
 }
-int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
+static int launch_linear_small_valu(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
     if (dtype == NSA_DT_F32) return linear_small_t<float>(A, W, out, M, N, K, st);
     if (dtype == NSA_DT_BF16) return linear_small_t<__bf16>(A, W, out, M, N, K, st);
     return linear_small_t<_Float16>(A, W, out, M, N, K, st);
@@ -196,8 +196,91 @@ __global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P
     }
 }
 
+// ---- MFMA form for 9 <= M rows (batched decode): workgroup = 16 output columns x 64 rows, the 4 waves split the K axis.
+// C^T[n, m] = W[n,:] . X[m,:]: W rows are the MFMA A operand (each W element is fetched once, straight from global in
+// fragment shape), the rows of X the B operand (L1/L2 resident), all loads of a wave issued before its first MFMA; the four
+// K-partials meet in LDS.  Thread t of the epilogue owns row m = t % 64 and columns 4 (t / 64) .. +3 (two rotation pairs).
+template <typename T, bool ROPE>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
+                                                          T *__restrict__ out, int M, int N, int K) {
+    using MT_ = MfmaT<T>;
+    using x8 = typename MT_::x8;
+    __shared__ float part[4][16][65];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), rho = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int ksteps = K / 32, per = (ksteps + 3) / 4;
+    const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const T *wrow = W + (int64_t)(n0 + rho) * K + 8 * q;
+    for (int sb = s0; sb < s1; sb += 6) {  // 6 k-steps (30 loads) in flight per round
+        x8 wf[6], xf[6][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int s = min(sb + i, s1 - 1);
+            wf[i] = *(const x8 *)(wrow + 32 * s);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = min(m0 + 16 * mt + rho, M - 1);
+                xf[i][mt] = *(const x8 *)(X + (int64_t)m * K + 32 * s + 8 * q);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (sb + i < s1) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = MT_::mma(wf[i], xf[i][mt], acc[mt]);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][4 * q + r][16 * mt + rho] = acc[mt][r];
+    __syncthreads();
+    const int m = m0 + (threadIdx.x & 63), nq = threadIdx.x >> 6;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 4 * nq + r, mm = threadIdx.x & 63;
+        v[r] = (part[0][n][mm] + part[1][n][mm]) + (part[2][n][mm] + part[3][n][mm]);
+    }
+    if (m >= M) return;
+    if (ROPE) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) rope_store_pair<T>(P, m, 0, n0 + 4 * nq + 2 * p, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(int64_t)m * N + n0 + 4 * nq + r] = Elt<T>::from_f(v[r]);
+    }
+}
+
+static bool linear_mfma_ok(int dtype, int M, int N, int K, const void *X, const void *W) {
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 9 && N % 16 == 0 && K % 32 == 0 &&
+           (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
+}
+
+int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
+    if (linear_mfma_ok(dtype, M, N, K, A, W)) {
+        RopeAppendParams P{};
+        const dim3 g2((unsigned)(N / 16), (unsigned)((M + 63) / 64));
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K);
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K);
+        NSA_LAUNCH_CHECK("linear_small(mfma)");
+        return NSA_OK;
+    }
+    return launch_linear_small_valu(A, W, out, M, N, K, dtype, st);
+}
+
 int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st) {
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    if (linear_mfma_ok(dtype, P.B, NT, K, X, W)) {
+        const dim3 g2((unsigned)(NT / 16), (unsigned)((P.B + 63) / 64));
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K);
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K);
+        NSA_LAUNCH_CHECK("qkv_rope_append(mfma)");
+        return NSA_OK;
+    }
     const dim3 grid((unsigned)((NT / 2 + 3) / 4)), block(256);
     if (dtype == NSA_DT_F32) hipLaunchKernelGGL(qkv_rope_append_kernel<float>, grid, block, 0, st, P, (const float *)X, (const float *)W, K);
     else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(qkv_rope_append_kernel<__bf16>, grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K);
