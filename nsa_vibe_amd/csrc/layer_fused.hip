@@ -96,40 +96,74 @@ static int launch_linear_small_valu(const void *A, const void *W, void *out, int
 }
 
 // ------------------------------------------------------------------------------------------ RoPE + cache append
+// prefill form.  A thread owns ONE column pair (its rotation frequency, destination tensor and column are computed once) and
+// walks the tokens: consecutive threads = consecutive columns, so loads and stores stay coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void rope_cache_append_kernel(RopeAppendParams P) {
     const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
     const int NT = NQ + 3 * GK + 3 * GV;
-    const int64_t npair = (int64_t)P.B * P.S * (NT / 2);
-    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < npair; it += (int64_t)gridDim.x * 256) {
-        const int64_t row = it / (NT / 2);
-        const int col = 2 * (int)(it - row * (NT / 2));
-        const int b = (int)(row / P.S), s = (int)(row - (int64_t)b * P.S);
-        const float pos = (float)(P.t0 + s);
-        const T *src = (const T *)P.proj + row * NT + col;
-        float x0 = Elt<T>::to_f(src[0]), x1 = Elt<T>::to_f(src[1]);
-        if (col < NQ) {  // Q: rotated over the flattened [n_heads * d_k] axis (reference :552-560, :1002-1009)
-            rope_pair<T>(x0, x1, col >> 1, NQ, pos, P.rope_base, P.inv_scale, x0, x1);
-            T *dst = (T *)P.Q_out + row * NQ + col;
-            dst[0] = Elt<T>::from_f(x0);
-            dst[1] = Elt<T>::from_f(x1);
-            continue;
-        }
-        // segments after Q: K_sel | V_sel | K_win | V_win | K_raw | V_raw   (K segments G*Dk wide, V segments G*Dv)
+    const int cp = blockIdx.x * 256 + threadIdx.x;
+    if (cp >= NT / 2) return;
+    const int col = 2 * cp;
+    // destination: base pointer + per-batch and per-token strides (elements), rotation: pair index i of D_rope (or none)
+    T *dst;
+    int64_t sb, ss;
+    int ri = -1, rD = 1;
+    if (col < NQ) {
+        dst = (T *)P.Q_out + col;
+        sb = (int64_t)P.S * NQ;
+        ss = NQ;
+        ri = col >> 1;
+        rD = NQ;
+    } else {
         int c = col - NQ;
         const int pairw = GK + GV;
-        const int sp = c / pairw;  // 0 sel, 1 win, 2 raw
+        const int sp = c / pairw;
         c -= sp * pairw;
         const bool isv = c >= GK;
         if (isv) c -= GK;
         const int D = isv ? P.Dv : P.Dk;
         const int g = c / D, dc = c - g * D;
-        if (!isv && sp < 2) rope_pair<T>(x0, x1, dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, x0, x1);  // K_sel, K_win per group
-        T *cache = (T *)P.cache[2 * sp + (isv ? 1 : 0)];
-        T *dst = cache + (((int64_t)b * P.G + g) * P.S_max + (P.t0 + s)) * D + dc;
-        dst[0] = Elt<T>::from_f(x0);
-        dst[1] = Elt<T>::from_f(x1);
+        dst = (T *)P.cache[2 * sp + (isv ? 1 : 0)] + ((int64_t)g * P.S_max + P.t0) * D + dc;
+        sb = (int64_t)P.G * P.S_max * D;
+        ss = D;
+        if (!isv && sp < 2) {
+            ri = dc >> 1;
+            rD = P.Dk;
+        }
     }
+    const float inv_freq = ri >= 0 ? powf(P.rope_base, (-2.0f * (float)ri) / (float)rD) : 0.f;
+    const int64_t ntok = (int64_t)P.B * P.S;
+    for (int64_t row = blockIdx.y; row < ntok; row += gridDim.y) {
+        const int b = (int)(row / P.S), s = (int)(row - (int64_t)b * P.S);
+        const T *src = (const T *)P.proj + row * NT + col;
+        float x0 = Elt<T>::to_f(src[0]), x1 = Elt<T>::to_f(src[1]);
+        if (ri >= 0) {
+            const float ang = ((float)(P.t0 + s) * P.inv_scale) * inv_freq;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            sn = rnd<T>(sn);
+            cs = rnd<T>(cs);
+            const float r0 = rnd<T>(rnd<T>(x0 * cs) - rnd<T>(x1 * sn));
+            x1 = rnd<T>(rnd<T>(x0 * sn) + rnd<T>(x1 * cs));
+            x0 = r0;
+        }
+        T *d = dst + b * sb + s * ss;
+        d[0] = Elt<T>::from_f(x0);
+        d[1] = Elt<T>::from_f(x1);
+    }
+}
+
+int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st) {
+    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    const int64_t ntok = (int64_t)P.B * P.S;
+    if (ntok == 0) return NSA_OK;
+    const dim3 grid((unsigned)((NT / 2 + 255) / 256), (unsigned)std::min<int64_t>(ntok, 2048));
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rope_cache_append_kernel<float>, grid, dim3(256), 0, st, P);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rope_cache_append_kernel<__bf16>, grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(rope_cache_append_kernel<_Float16>, grid, dim3(256), 0, st, P);
+    NSA_LAUNCH_CHECK("rope_cache_append");
+    return NSA_OK;
 }
 
 // decode form: the fused QKV projection and the RoPE + cache append in one kernel.  One wave per PAIR of adjacent output
@@ -289,17 +323,6 @@ int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void 
     return NSA_OK;
 }
 
-int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st) {
-    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
-    const int64_t npair = (int64_t)P.B * P.S * (NT / 2);
-    if (npair == 0) return NSA_OK;
-    const unsigned grid = (unsigned)std::min<int64_t>((npair + 255) / 256, 65536);
-    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rope_cache_append_kernel<float>, dim3(grid), dim3(256), 0, st, P);
-    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rope_cache_append_kernel<__bf16>, dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL(rope_cache_append_kernel<_Float16>, dim3(grid), dim3(256), 0, st, P);
-    NSA_LAUNCH_CHECK("rope_cache_append");
-    return NSA_OK;
-}
 
 // ------------------------------------------------------------------------------------------ compressed-token emission
 // one 64-thread block per (b, g, j): K_cmp[j] = mean_i rope(K_raw[j d + i], pos = j d + i), V_cmp[j] = mean_i V_raw[j d + i]
