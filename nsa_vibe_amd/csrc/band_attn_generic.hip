@@ -12,7 +12,6 @@ __global__ __launch_bounds__(256) void band_attn_fwd_generic_kernel(BandAttnPara
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nrh = (int64_t)P.B * P.S * P.G * P.h;
     if (wid >= nrh) return;
-    const int head = (int)(wid % P.h);
     const int64_t row = wid / P.h;
     const int g = (int)(row % P.G);
     const int64_t bt = row / P.G;

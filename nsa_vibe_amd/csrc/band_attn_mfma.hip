@@ -91,10 +91,10 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
                                                  __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     };
-    const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + G_::ROWB);
-    const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + G_::ROWB);
-    const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
-    const int kstep = uniform(G_::RPI * (int)krowb), vstep = uniform(G_::RPI * (int)vrowb);
+    [[maybe_unused]] const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + G_::ROWB);
+    [[maybe_unused]] const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + G_::ROWB);
+    [[maybe_unused]] const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    [[maybe_unused]] const int kstep = uniform(G_::RPI * (int)krowb), vstep = uniform(G_::RPI * (int)vrowb);
     const int ld_row = lane / G_::PIECES, ld_piece = lane % G_::PIECES;
     uint32_t kdma[G_::NLD], vdma[G_::NLD];
 #pragma unroll

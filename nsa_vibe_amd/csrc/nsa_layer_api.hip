@@ -131,7 +131,7 @@ int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const 
     hipStream_t st = (hipStream_t)stream;
     const int dt = L->dtype;
     const int G = L->G, h = L->h, Dk = L->Dk, Dv = L->Dv;
-    const int NQ = G * h * Dk, NO = G * h * Dv, NT = NQ + 3 * G * Dk + 3 * G * Dv;
+    const int NO = G * h * Dv;
     void *proj = ws + W.proj, *Q = ws + W.q, *Ocmp = ws + W.ocmp, *Osel = ws + W.osel, *Owin = ws + W.owin, *Omix = ws + W.omix;
     int32_t *ranges = ranges_out ? ranges_out : (int32_t *)(ws + W.ranges);
 

@@ -156,10 +156,10 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(SelAttnBwdParams P, const f
         return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
                                                  __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     };
-    const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + BROWB);
-    const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + BROWB);
-    const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
-    const int kstep = uniform(8 * (int)krowb), vstep = uniform(8 * (int)vrowb);
+    [[maybe_unused]] const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + BROWB);
+    [[maybe_unused]] const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + BROWB);
+    [[maybe_unused]] const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    [[maybe_unused]] const int kstep = uniform(8 * (int)krowb), vstep = uniform(8 * (int)vrowb);
 
     int it_seg = -1, it_start = 0, it_len = 0, it_pos = 0;
     auto next_tile = [&](int &tok0, int &nvalid) -> bool {
