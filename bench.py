@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+L2_PEAK_GBPS = 34500.0  # same guide, "L2 (per XCD)": 32 MiB aggregate, ~34.5 TB/s
 
 G, H, D = 2, 6, 64
 L_CMP, D_CMP, L_SEL, N_SEL = 32, 16, 64, 16
@@ -308,6 +309,9 @@ def main():
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(S, B),
                            "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01/traffic_*.json); the gather is "
                                            "L2 / Infinity-Cache resident, so achieved (algorithmic) exceeds what reaches HBM",
+                           "l2_peak": L2_PEAK_GBPS, "l2_frac": achieved / L2_PEAK_GBPS,
+                           "l2_note": "the XCD-aware (b,g)-major order keeps one pair's K/V (1 MiB at S=4096) in its XCD's 4 MiB L2: the gather "
+                                      "runs against the aggregate L2 bandwidth, not HBM",
                            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
                            "mfma_tflops": flops / (t_att * 1e-3) / 1e12, "mfma_frac": flops / (t_att * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att}
