@@ -156,12 +156,15 @@ def layer_bench(nv, B, S, device, steps=40):
         xt = torch.randn(B, 1, 768, device=device, dtype=torch.bfloat16)
         for _ in range(8):
             _, kv = m(xt, kv, prefill=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            _, kv = m(xt, kv, prefill=False)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        # blocks of 10 steps, best block: a shared box shows occasional multi-millisecond stalls unrelated to the work
+        dt = 1e9
+        for _ in range(max(1, steps // 10)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                _, kv = m(xt, kv, prefill=False)
+            torch.cuda.synchronize()
+            dt = min(dt, (time.perf_counter() - t0) / 10)
     return {"prefill_ms": best * 1e3, "prefill_tok_per_s": B * S / best, "decode_us_per_step": dt * 1e6, "decode_tok_per_s": B / dt}
 
 

@@ -423,12 +423,20 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
     const size_t a = align16(nsa_sel_scores_workspace(B, 1, G, h, Dk, S_cmp, S_sel, 0, 0, 0, dtype, 3));
     const size_t p = align16(sizeof(float) * (size_t)B * G * (size_t)(S_sel > 0 ? S_sel : 1));
     float *p_grp = (float *)(w + a);
-    int rc = nsa_sel_scores(Q, K_cmp, p_grp, B, 1, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l, d, l_sel, 1,
+    int rc;
+    if (decode_score_select_supported(dtype, h, Dk, S_cmp, S_sel, kcb, kcg, kcs, Q, K_cmp)) {
+        // scores -> statistics -> Eq.9/10 -> sequential top-n in one launch (bit-identical to the route below)
+        rc = launch_decode_score_select(Q, K_cmp, B, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token,
+                                        dtype, scale > 0.f ? scale : 1.0f / sqrtf((float)Dk), ranges_out, (hipStream_t)stream);
+        if (rc) return rc;
+    } else {
+        rc = nsa_sel_scores(Q, K_cmp, p_grp, B, 1, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l, d, l_sel, 1,
                             S_cmp >= 1 ? 3 : 1, dtype, scale, w, a, stream);
-    if (rc) return rc;
-    rc = nsa_select_topn_ranges(p_grp, (int64_t)B * G, 1, G, t_token, nullptr, S_sel, l_sel, n_top, 1, 2, NSA_SEL_SEQUENTIAL, 1,
-                                ranges_out, n_top, stream);
-    if (rc) return rc;
+        if (rc) return rc;
+        rc = nsa_select_topn_ranges(p_grp, (int64_t)B * G, 1, G, t_token, nullptr, S_sel, l_sel, n_top, 1, 2, NSA_SEL_SEQUENTIAL, 1,
+                                    ranges_out, n_top, stream);
+        if (rc) return rc;
+    }
     if (part_used) *part_used = (float *)(w + a + p);
     return sel_attn_fwd_impl(Q, K, V, ranges_out, O, nullptr, B, 1, G, h, Dk, Dv, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, dtype, scale, 0,
                              w + a + p, workspace_bytes - a - p, stream, defer, ns_used);

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 namespace nsa {
 
 int sel_attn_fwd_impl(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, float *lse, int B, int S, int G, int h,
@@ -17,5 +19,11 @@ int sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, const 
                          int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb,
                          int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *workspace,
                          size_t workspace_bytes, void *stream, int defer, int *ns_used, float **part_used);
+
+bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_sel, int64_t csb, int64_t csg, int64_t css, const void *Q,
+                                   const void *Kc);
+int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg, int64_t css,
+                               const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,
+                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st);
 
 }  // namespace nsa

@@ -9,7 +9,10 @@
 // CPU scatter_add visits the COO entries), then sums the heads in ascending h.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "nsa_common.hpp"
+#include "sel_select_row.hpp"
 
 namespace nsa {
 
@@ -366,6 +369,208 @@ __global__ __launch_bounds__(64) void decode_pgrp_kernel(DecodeParams P) {
         }
     }
     P.p_grp[row * (int64_t)P.S_sel + j] = grp;
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode, fused: logits -> statistics -> Eq.9/10 -> top-n ranges in ONE launch.  One 1024-thread workgroup per query row
+// (b,g): the logits of the row ([h, S_cmp] fp32, 98 KB at 64k context) and its group scores stay in LDS, phases are separated
+// by workgroup barriers.  The arithmetic of every phase is the arithmetic of decode_logits_mfma_kernel, decode_pgrp_kernel
+// and select_topn_kernel (same operations, same order), so p_grp and the ranges are bit-identical to the 3-kernel route;
+// it exists because a decode step is a chain of tiny launches and each one costs ~5 us of latency.
+// ---------------------------------------------------------------------------------------
+template <typename T, int KSTEPS>
+__global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams P, SelectParams SP, int cand, int t_token) {
+    typedef typename std::conditional<std::is_same<T, __bf16>::value, bf16x8, f16x8>::type x8;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6), rho = lane & 15, q = lane >> 4;
+    constexpr int NW = 16;
+    const int64_t row = blockIdx.x;
+    const int nchunk = dec_nchunk(P.S_cmp);
+    float *xs = dsm;                                   // [h][S_cmp]
+    float *part = xs + (size_t)P.h * P.S_cmp;          // [h][nchunk][2]
+    float *mlog_s = part + (size_t)P.h * nchunk * 2;   // [64]
+    float *pg = mlog_s + 64;                           // [S_sel]
+    const int g = (int)(row % P.G);
+    const int b = (int)(row / ((int64_t)P.G * P.S));
+    constexpr int Dk = 32 * KSTEPS;
+    // ---- phase 1: logits of 64 compressed rows per wave and step (MFMA rows), heads = columns
+    {
+        x8 qf[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (rho < P.h) raw = *(const u32x4 *)((const T *)P.Q + (row * P.h + rho) * (int64_t)Dk + 32 * s + 8 * q);
+            qf[s] = __builtin_bit_cast(x8, raw);
+        }
+        const T *kb = (const T *)P.Kc + (int64_t)b * P.csb + (int64_t)g * P.csg;
+        for (int chunk = wave; chunk < nchunk; chunk += NW) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = min(chunk * 64 + 16 * u + rho, P.S_cmp - 1);
+                acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const x8 a = *(const x8 *)(kb + (int64_t)c * P.css + 32 * s + 8 * q);
+                    if constexpr (std::is_same<T, __bf16>::value) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[s], acc[u], 0, 0, 0);
+                    else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[s], acc[u], 0, 0, 0);
+                }
+            }
+            float m = -INFINITY;
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = chunk * 64 + 16 * u + 4 * q + j;
+                    const float v = acc[u][j] * P.c2;
+                    x[4 * u + j] = v;
+                    if (c < P.S_cmp) {
+                        if (rho < P.h) xs[(size_t)rho * P.S_cmp + c] = v;
+                        m = fmaxf(m, v);
+                    }
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (chunk * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(x[4 * u + j] - m);
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            if (q == 0 && rho < P.h) {
+                float *pr = part + ((size_t)rho * nchunk + chunk) * 2;
+                pr[0] = m;
+                pr[1] = l;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2a: softmax statistics per head (one wave per head)
+    for (int hh = wave; hh < P.h; hh += NW) {
+        const float *pr = part + (size_t)hh * nchunk * 2;
+        float m, l;
+        if (nchunk <= 64) {
+            const float mv = lane < nchunk ? pr[2 * lane] : -INFINITY;
+            const float lv = lane < nchunk ? pr[2 * lane + 1] : 0.f;
+            m = wave_max(mv);
+            l = wave_sum(lane < nchunk ? lv * __builtin_amdgcn_exp2f(mv - m) : 0.f);
+        } else {
+            m = -INFINITY;
+            for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, pr[2 * c]);
+            m = wave_max(m);
+            l = 0.f;
+            for (int c = lane; c < nchunk; c += 64) l += pr[2 * c + 1] * __builtin_amdgcn_exp2f(pr[2 * c] - m);
+            l = wave_sum(l);
+        }
+        if (lane == 0) mlog_s[hh] = m + __builtin_amdgcn_logf(l);
+    }
+    __syncthreads();
+    // ---- phase 2b: Eq.9 taps + Eq.10 head sum, lane = selection block
+    for (int jb = wave; jb * 64 < P.S_sel; jb += NW) {
+        const int j = jb * 64 + lane;
+        if (j >= P.S_sel) continue;
+        const int k0 = P.csc_ptr[j], k1 = P.csc_ptr[j + 1];
+        float grp = 0.f;
+        if (k1 - k0 <= 8) {  // taps once (global), logits from LDS
+            int rr[8];
+            float vv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool ok = k0 + t < k1;
+                const int r = ok ? P.csc_rows[k0 + t] : P.S_cmp;
+                rr[t] = r < P.S_cmp ? r : -1;
+                vv[t] = ok ? P.csc_vals[k0 + t] : 0.f;
+            }
+            for (int hh = 0; hh < P.h; ++hh) {
+                const float *x = xs + (size_t)hh * P.S_cmp;
+                const float ml = mlog_s[hh];
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (rr[t] >= 0) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[rr[t]] - ml), vv[t]));
+                grp = __fadd_rn(grp, acc);
+            }
+        } else {
+            for (int hh = 0; hh < P.h; ++hh) {
+                const float *x = xs + (size_t)hh * P.S_cmp;
+                const float ml = mlog_s[hh];
+                float acc = 0.f;
+                for (int k = k0; k < k1; ++k) {
+                    const int r = P.csc_rows[k];
+                    if (r < P.S_cmp) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[r] - ml), P.csc_vals[k]));
+                }
+                grp = __fadd_rn(grp, acc);
+            }
+        }
+        pg[j] = grp;
+    }
+    __syncthreads();
+    // ---- phase 3: top-n + forced blocks + merge (one wave)
+    if (wave == 0) {
+        int32_t *out = SP.out + row * (int64_t)SP.W * 2;
+        switch (cand) {
+            case 1: select_topn_row<1>(SP, pg, t_token, out); break;
+            case 2: select_topn_row<2>(SP, pg, t_token, out); break;
+            case 4: select_topn_row<4>(SP, pg, t_token, out); break;
+            case 8: select_topn_row<8>(SP, pg, t_token, out); break;
+            case 16: select_topn_row<16>(SP, pg, t_token, out); break;
+            default: select_topn_row<32>(SP, pg, t_token, out); break;
+        }
+    }
+}
+
+static size_t decode_fused_lds(int h, int S_cmp, int S_sel) {
+    return sizeof(float) * ((size_t)h * S_cmp + (size_t)h * dec_nchunk(S_cmp) * 2 + 64 + (size_t)S_sel);
+}
+
+// fused route available?  (bf16/f16 MFMA shapes, the row's logits fit in LDS)
+bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_sel, int64_t csb, int64_t csg, int64_t css, const void *Q,
+                                   const void *Kc) {
+    if (getenv("NSA_HIP_DECODE_UNFUSED")) return false;  // A/B switch for measurements and for the equivalence test
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && (Dk == 64 || Dk == 128) && h <= 16 && S_cmp >= 1 && S_sel >= 1 &&
+           S_sel <= 64 * 32 && css % 8 == 0 && csb % 8 == 0 && csg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)Kc % 16 == 0) &&
+           S_cmp <= 2048 &&  // beyond ~32k context the wider 3-kernel route wins (measured: 64k 73.6 vs 79.8 us per layer step)
+           decode_fused_lds(h, S_cmp, S_sel) <= 150 * 1024;
+}
+
+int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg, int64_t css,
+                               const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,
+                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st) {
+    const int64_t R = (int64_t)B * G;
+    NSA_CHECK_ARG(R <= 65535 * 32, "decode scorer: too many rows");
+    DecodeParams P{Q, Kc, nullptr, nullptr, nullptr, csc_ptr, csc_rows, csc_vals, R, 1, G, h, Dk, S_cmp, S_sel, csb, csg, css, scale * LOG2E};
+    SelectParams SP{};
+    if (int rc = select_params_sequential(&SP, S_sel, l_sel, n_top, 1, 2, n_top)) return rc;
+    SP.out = ranges_out;
+    SP.R = R;
+    SP.S = 1;
+    SP.G = G;
+    SP.t0 = t_token;
+    const int c = (S_sel + 63) / 64;
+    const int cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : c <= 16 ? 16 : 32;
+    const size_t lds = decode_fused_lds(h, S_cmp, S_sel);
+    void (*k)(DecodeParams, SelectParams, int, int);
+    if (dtype == NSA_DT_BF16) k = Dk == 64 ? decode_score_select_kernel<__bf16, 2> : decode_score_select_kernel<__bf16, 4>;
+    else k = Dk == 64 ? decode_score_select_kernel<_Float16, 2> : decode_score_select_kernel<_Float16, 4>;
+    if (lds > 64 * 1024) {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
+        static void *raised[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool done = false;
+        for (void *r : raised) done |= (r == (void *)k);
+        if (!done) {
+            NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (void *&r : raised)
+                if (!r) {
+                    r = (void *)k;
+                    break;
+                }
+        }
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)R), dim3(1024), lds, st, P, SP, cand, t_token);
+    NSA_LAUNCH_CHECK("decode_score_select");
+    return NSA_OK;
 }
 
 size_t decode_scores_workspace(int64_t R, int h, int S_cmp) {

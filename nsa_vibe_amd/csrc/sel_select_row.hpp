@@ -1,0 +1,148 @@
+// Top-n selection of one row by one wave (shared by select_topn_kernel and the fused decode scorer).
+#pragma once
+#include "nsa_common.hpp"
+
+namespace nsa {
+
+struct SelectParams {
+    const float *p_grp;     // [R,S_sel]
+    const int32_t *t_rows;  // [R] or null
+    int32_t *out;           // [R,W,2]
+    int64_t R;
+    int S, G, t0, S_sel, l_sel, n_top, force_init, force_local, mode, W;
+    int k_actual;      // picks per row
+    int n_forced;      // forced entries used (sequential: all; batched: kept columns, maybe truncated)
+    unsigned keepmask; // batched: bit i = sorted forced column i is kept
+    int all_valid;     // batched with n_top >= S_sel: select every valid block
+};
+
+// one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS), out = its [W,2] ranges.
+template <int CAND>
+__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out) {
+    const int lane = lane_id();
+    const int l_sel = P.l_sel, S_sel = P.S_sel;
+    const int nvalid_blocks = min(S_sel, (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
+
+    float key[CAND];
+    unsigned selbits = 0;  // bit c = block lane + 64 c selected
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        const int j = lane + 64 * c;
+        float k = -INFINITY;
+        if (j < nvalid_blocks) k = __fsub_rn(p[j], __fmul_rn((float)j, 1e-8f));
+        key[c] = k;
+        if (P.all_valid && j < nvalid_blocks) selbits |= 1u << c;
+    }
+
+    if (!P.all_valid) {
+        // ---- forced blocks
+        const int cblk = max(t / l_sel, 0);
+        const int nf_all = (P.force_init ? 1 : 0) + P.force_local;
+        int used = 0;
+        for (int i = 0; i < nf_all; ++i) {
+            // sorted forced list: [0 (init)] then max(cblk - a, 0) with a descending to 0
+            int f;
+            if (P.force_init && i == 0) f = 0;
+            else f = max(cblk - (nf_all - 1 - i), 0);
+            if (P.mode == NSA_SEL_BATCHED) {
+                if (!((P.keepmask >> i) & 1u)) continue;
+                if (used >= P.n_forced) break;
+            }
+            ++used;
+            if (f >= S_sel) continue;
+            const bool valid = f < nvalid_blocks;
+            if ((f & 63) == lane) {
+                const int c = f >> 6;
+#pragma unroll
+                for (int cc = 0; cc < CAND; ++cc)
+                    if (cc == c) {
+                        key[cc] = -INFINITY;                                              // excluded from top-k
+                        if (P.mode == NSA_SEL_SEQUENTIAL || valid) selbits |= 1u << cc;   // batched drops invalid picks
+                    }
+            }
+        }
+        // ---- top-k picks: threshold (radix) select on an order-preserving integer image of the key.
+        // 32 rounds of {compare, ballot, popcount} find the k-th largest key T; everything above T is picked and the
+        // remaining slots go to the keys equal to T in ascending index order -- exactly (key desc, idx asc), with no
+        // cross-lane data movement (the iterative arg-max needed 12 dependent ds_bpermute per pick).
+        unsigned u[CAND];
+        int nv = 0;
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            const unsigned bits = __float_as_uint(key[c]);
+            const bool ok = key[c] > -INFINITY;  // forced / masked / NaN candidates never compete
+            u[c] = ok ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0u;  // valid keys map to >= 0x00800000
+            nv += __popcll(__ballot(ok));
+        }
+        const int k_eff = min(P.k_actual, nv);
+        if (k_eff > 0) {
+            unsigned T = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = T | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int c = 0; c < CAND; ++c) cnt += __popcll(__ballot(u[c] >= cand));
+                if (cnt >= k_eff) T = cand;
+            }
+            int cnt_gt = 0;
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) cnt_gt += __popcll(__ballot(u[c] > T));
+            int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
+                const bool eq = u[c] == T;
+                const unsigned long long em = __ballot(eq);
+                const int take = min(__popcll(em), remaining);
+                if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1u << c;
+                remaining -= take;
+            }
+        }
+    }
+
+    // ---- run extraction
+    int my_s = 0, my_e = 0;
+    int nrun = 0;
+    int cur_s = -1, cur_e = -1;  // pending run (block ids), wave uniform
+    auto emit = [&]() {
+        if (nrun == lane) {
+            my_s = cur_s * l_sel;
+            my_e = min((cur_e + 1) * l_sel, t + 1);
+        }
+        ++nrun;
+    };
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        unsigned long long w = __ballot((selbits >> c) & 1u);
+        while (w) {  // maximal runs of ones of this word, ascending
+            const int sb = __builtin_ctzll(w);
+            const unsigned long long inv = ~(w >> sb);
+            const int len = inv ? __builtin_ctzll(inv) : 64;
+            const unsigned long long ones = (len == 64) ? ~0ull : ((1ull << len) - 1ull);
+            w &= ~(ones << sb);
+            const int s_blk = 64 * c + sb, e_blk = s_blk + len - 1;
+            if (cur_s >= 0 && s_blk == cur_e + 1) {
+                cur_e = e_blk;  // run continues across the word boundary
+            } else {
+                if (cur_s >= 0) emit();
+                cur_s = s_blk;
+                cur_e = e_blk;
+            }
+        }
+    }
+    if (cur_s >= 0) emit();
+    if (lane < P.W) {
+        out[2 * lane] = my_s;
+        out[2 * lane + 1] = my_e;
+    }
+    // rows wider than a wave (W > 64 only when n_top >= S_sel > 64: a single run) -> zero the rest
+    for (int i = lane + 64; i < P.W; i += 64) {
+        out[2 * i] = 0;
+        out[2 * i + 1] = 0;
+    }
+}
+
+// host: SelectParams of the sequential selector (decode / per-row prefill), see sel_select.hip
+int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, int force_init, int force_local, int W);
+
+}  // namespace nsa

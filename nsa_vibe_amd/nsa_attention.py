@@ -268,20 +268,22 @@ class NSAAttention(nn.Module):
         num_cmp = 0 if S_raw < self.l else (S_raw - self.l) // self.d + 1
         L = _lib.lib()
         desc, _ = self._layer_desc()
-        kd = self._kv_desc(kv)
-        ws = workspace(dev, L.nsa_layer_decode_step_workspace(ctypes.byref(desc), B, kd.S_max) + 256, "layer_decode")
-        wptr = (ws.data_ptr() + 255) & ~255
+        ctx = getattr(kv, "_dec_ctx", None)  # per-cache constants of the native call (descriptors, workspace, monitors)
+        if ctx is None or ctx[0] is not desc:
+            kd = self._kv_desc(kv)
+            ws = workspace(dev, L.nsa_layer_decode_step_workspace(ctypes.byref(desc), B, kd.S_max) + 256, "layer_decode")
+            wptr = (ws.data_ptr() + 255) & ~255
+            ranges = torch.empty((B, self.n_kv_groups, self.n_sel, 2), dtype=torch.int32, device=dev)
+            gates = torch.empty((B, 1, self.n_kv_groups, 3), dtype=torch.float32, device=dev)
+            ctx = kv._dec_ctx = (desc, ctypes.byref(desc), ctypes.byref(kd), kd, ws, wptr, ws.numel() - (wptr - ws.data_ptr()), ranges, gates)
+        _, desc_ref, kd_ref, _, _, wptr, wsize, ranges, gates = ctx
         cptr, crows, cvals = kv.meta.device_csc(dev)
-        xc = x.reshape(B, self.dim).contiguous()
+        xc = x.reshape(B, self.dim)
+        if not xc.is_contiguous():
+            xc = xc.contiguous()
         y = torch.empty((B, 1, self.dim), dtype=x.dtype, device=dev)
-        mon = getattr(kv, "_monitors", None)  # ranges / gates of the latest step (overwritten every step)
-        if mon is None:
-            mon = kv._monitors = (torch.empty((B, self.n_kv_groups, self.n_sel, 2), dtype=torch.int32, device=dev),
-                                  torch.empty((B, 1, self.n_kv_groups, 3), dtype=torch.float32, device=dev))
-        ranges, gates = mon
-        rc = L.nsa_layer_decode_step(ctypes.byref(desc), ctypes.byref(kd), xc.data_ptr(), y.data_ptr(), t, cptr.data_ptr(),
-                                     crows.data_ptr(), cvals.data_ptr(), int(kv.meta.S_sel), ranges.data_ptr(), gates.data_ptr(),
-                                     wptr, ws.numel() - (wptr - ws.data_ptr()), _stream(dev))
+        rc = L.nsa_layer_decode_step(desc_ref, kd_ref, xc.data_ptr(), y.data_ptr(), t, cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(),
+                                     int(kv.meta.S_sel), ranges.data_ptr(), gates.data_ptr(), wptr, wsize, _stream(dev))
         _lib.check(rc, "nsa_layer_decode_step")
         kv.t, kv.n_cmp = S_raw, num_cmp
         kv.append_reads(num_cmp, S_raw)
