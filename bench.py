@@ -67,7 +67,8 @@ def time_events(fn, iters, warm=2):
         fn()
         b.record()
     torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
+    # median: equals the mean for these kernels except when the shared box inserts a rare multi-millisecond stall
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))  # ms
 
 
 def stage_times(nv, meta, Q, Kc, K, V, S, iters):
