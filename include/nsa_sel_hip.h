@@ -154,6 +154,19 @@ NSA_API int nsa_cmp_pool_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, 
 /* Gate MLP + combine (nsa_attention.py:32-82, 85-124): O_out = sum_i gate_i O_i; gates_out [R,3] fp32 nullable; R = B*S*G rows. */
 NSA_API int nsa_gate_combine(const nsa_layer_desc *L, const void *Q, const void *O_cmp, const void *O_sel, const void *O_win,
                      void *O_out, float *gates_out, int64_t R, void *stream);
+/* Backward of the three layer kernels (training path; the attention branches have their own backward entry points).
+ *   rope_cache_append_bwd: dQ [B,S,G,h,Dk] and the gradients of the S appended rows of each cache, [B,G,S,D] contiguous
+ *                          (NULL = zero), -> dproj [B,S,NQ+3GDk+3GDv] (the rotation is undone on the gradient).
+ *   cmp_pool_bwd:          dK_cmp/dV_cmp [B,G,n_cmp,D] -> dK_raw/dV_raw [B,G,S,D]  (raw rows 0..S-1, windows j d .. j d + l).
+ *   gate_combine_bwd:      dO [R,h,Dv] -> dO_cmp/dO_sel/dO_win = gate_i dO and dgates [R,3] fp32 = sum O_i dO;
+ *                          the gradient through the gate MLP (a [R,Dk] -> [R,3] network) is left to the caller. */
+NSA_API int nsa_rope_cache_append_bwd(const nsa_layer_desc *L, int B, int S, int t0, const void *dQ, const void *dK_sel,
+                              const void *dV_sel, const void *dK_win, const void *dV_win, const void *dK_raw,
+                              const void *dV_raw, void *dproj, void *stream);
+NSA_API int nsa_cmp_pool_bwd(const nsa_layer_desc *L, int B, int S, int n_cmp, const void *dK_cmp, const void *dV_cmp, void *dK_raw,
+                     void *dV_raw, void *stream);
+NSA_API int nsa_gate_combine_bwd(const nsa_layer_desc *L, const void *dO, const void *O_cmp, const void *O_sel, const void *O_win,
+                         const float *gates, void *dO_cmp, void *dO_sel, void *dO_win, float *dgates, int64_t R, void *stream);
 /* One decode step of the whole layer in one call (nsa_attention.py:509-830, decode branch): x [B,dim] is the new token at
  * position t (= tokens already cached); appends it to the caches, emits a compressed token when due, runs the three branches,
  * the gate and the output projection -> y [B,dim].  csc_* / S_sel: the Eq.9 map of the block metadata covering t

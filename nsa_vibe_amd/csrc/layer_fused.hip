@@ -166,6 +166,80 @@ int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t s
     return NSA_OK;
 }
 
+// backward of rope_cache_append: d(proj) from dQ [B,S,NQ] and the six cache-slice gradients [B,G,S,D] (null = zero).  The
+// rotation is orthogonal, so the gradient of a rotated pair is the pair rotated back by the same angle.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_cache_append_bwd_kernel(RopeAppendParams P) {
+    const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
+    const int NT = NQ + 3 * GK + 3 * GV;
+    const int cp = blockIdx.x * 256 + threadIdx.x;
+    if (cp >= NT / 2) return;
+    const int col = 2 * cp;
+    const T *src;  // gradient of the forward's destination
+    int64_t sb, ss;
+    int ri = -1, rD = 1;
+    if (col < NQ) {
+        src = (const T *)P.Q_out + col;
+        sb = (int64_t)P.S * NQ;
+        ss = NQ;
+        ri = col >> 1;
+        rD = NQ;
+    } else {
+        int c = col - NQ;
+        const int pairw = GK + GV;
+        const int sp = c / pairw;
+        c -= sp * pairw;
+        const bool isv = c >= GK;
+        if (isv) c -= GK;
+        const int D = isv ? P.Dv : P.Dk;
+        const int g = c / D, dc = c - g * D;
+        const T *base = (const T *)P.cache[2 * sp + (isv ? 1 : 0)];  // [B,G,S,D] gradient tensor (S rows, not S_max)
+        src = base ? base + (int64_t)g * P.S * D + dc : nullptr;
+        sb = (int64_t)P.G * P.S * D;
+        ss = D;
+        if (!isv && sp < 2) {
+            ri = dc >> 1;
+            rD = P.Dk;
+        }
+    }
+    const float inv_freq = ri >= 0 ? powf(P.rope_base, (-2.0f * (float)ri) / (float)rD) : 0.f;
+    const int64_t ntok = (int64_t)P.B * P.S;
+    for (int64_t row = blockIdx.y; row < ntok; row += gridDim.y) {
+        const int b = (int)(row / P.S), s = (int)(row - (int64_t)b * P.S);
+        float g0 = 0.f, g1 = 0.f;
+        if (src) {
+            const T *p = src + b * sb + s * ss;
+            g0 = Elt<T>::to_f(p[0]);
+            g1 = Elt<T>::to_f(p[1]);
+        }
+        if (ri >= 0) {
+            const float ang = ((float)(P.t0 + s) * P.inv_scale) * inv_freq;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            sn = rnd<T>(sn);
+            cs = rnd<T>(cs);
+            const float r0 = g0 * cs + g1 * sn;  // y0 = x0 c - x1 s, y1 = x0 s + x1 c  =>  dx0 = g0 c + g1 s, dx1 = -g0 s + g1 c
+            g1 = g1 * cs - g0 * sn;
+            g0 = r0;
+        }
+        T *d = (T *)P.proj + row * NT + col;
+        d[0] = Elt<T>::from_f(g0);
+        d[1] = Elt<T>::from_f(g1);
+    }
+}
+
+int launch_rope_cache_append_bwd(const RopeAppendParams &P, int dtype, hipStream_t st) {
+    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    const int64_t ntok = (int64_t)P.B * P.S;
+    if (ntok == 0) return NSA_OK;
+    const dim3 grid((unsigned)((NT / 2 + 255) / 256), (unsigned)std::min<int64_t>(ntok, 2048));
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rope_cache_append_bwd_kernel<float>, grid, dim3(256), 0, st, P);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rope_cache_append_bwd_kernel<__bf16>, grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(rope_cache_append_bwd_kernel<_Float16>, grid, dim3(256), 0, st, P);
+    NSA_LAUNCH_CHECK("rope_cache_append_bwd");
+    return NSA_OK;
+}
+
 // decode form: the fused QKV projection and the RoPE + cache append in one kernel.  One wave per PAIR of adjacent output
 // columns (a rotation pair), rows of x in chunks of 8; lane r of the wave finishes row r of the chunk.
 template <typename T>
@@ -366,6 +440,58 @@ int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st) {
     return NSA_OK;
 }
 
+// backward of the pooling: raw row r receives 1/l of the gradient of every compressed token whose window contains it
+// (K: rotated back by the angle of position r).  dK_cmp/dV_cmp [nbg, n_cmp, D] -> dK_raw/dV_raw [nbg, S, D] (S rows).
+template <typename T>
+__global__ __launch_bounds__(64) void cmp_pool_bwd_kernel(CmpPoolParams P, const T *__restrict__ dKc, const T *__restrict__ dVc,
+                                                          T *__restrict__ dKr, T *__restrict__ dVr, int S, int n_cmp) {
+    const int r = (int)(blockIdx.x % S);
+    const int bg = (int)(blockIdx.x / S);
+    // windows j with j d <= r < j d + l
+    const int jhi = min(n_cmp - 1, r / P.d);
+    const int jlo = max(0, (r - P.l + P.d) / P.d);  // ceil((r - l + 1) / d) for r - l + 1 > 0, else 0
+    const float inv_l = 1.0f / (float)P.l;
+    for (int p = threadIdx.x; p < P.Dk / 2; p += 64) {
+        float g0 = 0.f, g1 = 0.f;
+        for (int j = jlo; j <= jhi; ++j) {
+            if (j * P.d + P.l <= r) continue;
+            const T *src = dKc + ((int64_t)bg * n_cmp + j) * P.Dk + 2 * p;
+            g0 += Elt<T>::to_f(src[0]);
+            g1 += Elt<T>::to_f(src[1]);
+        }
+        g0 *= inv_l;
+        g1 *= inv_l;
+        const float inv_freq = powf(P.rope_base, (-2.0f * (float)p) / (float)P.Dk);
+        float sn, cs;
+        sincosf(((float)r * P.inv_scale) * inv_freq, &sn, &cs);
+        sn = rnd<T>(sn);
+        cs = rnd<T>(cs);
+        T *dst = dKr + ((int64_t)bg * S + r) * P.Dk + 2 * p;
+        dst[0] = Elt<T>::from_f(g0 * cs + g1 * sn);
+        dst[1] = Elt<T>::from_f(g1 * cs - g0 * sn);
+    }
+    for (int c = threadIdx.x; c < P.Dv; c += 64) {
+        float g = 0.f;
+        for (int j = jlo; j <= jhi; ++j) {
+            if (j * P.d + P.l <= r) continue;
+            g += Elt<T>::to_f(dVc[((int64_t)bg * n_cmp + j) * P.Dv + c]);
+        }
+        dVr[((int64_t)bg * S + r) * P.Dv + c] = Elt<T>::from_f(g * inv_l);
+    }
+}
+
+int launch_cmp_pool_bwd(const CmpPoolParams &P, const void *dKc, const void *dVc, void *dKr, void *dVr, int S, int n_cmp, int dtype,
+                        hipStream_t st) {
+    const int64_t nblk = (int64_t)P.nbg * S;
+    if (nblk <= 0) return NSA_OK;
+    NSA_CHECK_ARG(nblk < ((int64_t)1 << 31), "cmp_pool_bwd: too many blocks");
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(cmp_pool_bwd_kernel<float>, dim3((unsigned)nblk), dim3(64), 0, st, P, (const float *)dKc, (const float *)dVc, (float *)dKr, (float *)dVr, S, n_cmp);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(cmp_pool_bwd_kernel<__bf16>, dim3((unsigned)nblk), dim3(64), 0, st, P, (const __bf16 *)dKc, (const __bf16 *)dVc, (__bf16 *)dKr, (__bf16 *)dVr, S, n_cmp);
+    else hipLaunchKernelGGL(cmp_pool_bwd_kernel<_Float16>, dim3((unsigned)nblk), dim3(64), 0, st, P, (const _Float16 *)dKc, (const _Float16 *)dVc, (_Float16 *)dKr, (_Float16 *)dVr, S, n_cmp);
+    NSA_LAUNCH_CHECK("cmp_pool_bwd");
+    return NSA_OK;
+}
+
 // ------------------------------------------------------------------------------------------ gate MLP + combine
 // one wave per (b, s, g) row: q_pooled = mean_h Q -> fc1 -> silu -> fc2 -> / tau -> softmax (one-hot when the top two
 // logits are more than 50 apart, nsa_attention.py:70-81) -> O = g_cmp O_cmp + g_sel O_sel + g_win O_win
@@ -525,6 +651,49 @@ __global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) 
     T *Oo = (T *)P.O_out + base;
     for (int e = lane; e < P.h * P.Dv; e += 64)
         Oo[e] = Elt<T>::from_f(mix3<T>(pr, Elt<T>::to_f(Oc[e]), Elt<T>::to_f(Os[e]), Elt<T>::to_f(Ow[e])));
+}
+
+// backward of the combine: dO_i = gate_i dO (activation dtype) and dgate_i = sum_{h,d} O_i dO (fp32) per row; the gradient of
+// the tiny gate MLP itself is taken by the host side from dgate.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_combine_bwd_kernel(GateCombineParams P, const T *__restrict__ dO, const float *__restrict__ gates,
+                                                               T *__restrict__ dOc, T *__restrict__ dOs, T *__restrict__ dOw,
+                                                               float *__restrict__ dgates) {
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= P.R) return;
+    const float g0 = gates[row * 3], g1 = gates[row * 3 + 1], g2 = gates[row * 3 + 2];
+    const int64_t base = row * P.h * P.Dv;
+    const T *Oc = (const T *)P.O_cmp + base, *Os = (const T *)P.O_sel + base, *Ow = (const T *)P.O_win + base;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int e = lane; e < P.h * P.Dv; e += 64) {
+        const float d = Elt<T>::to_f(dO[base + e]);
+        a0 = fmaf(Elt<T>::to_f(Oc[e]), d, a0);
+        a1 = fmaf(Elt<T>::to_f(Os[e]), d, a1);
+        a2 = fmaf(Elt<T>::to_f(Ow[e]), d, a2);
+        dOc[base + e] = Elt<T>::from_f(g0 * d);
+        dOs[base + e] = Elt<T>::from_f(g1 * d);
+        dOw[base + e] = Elt<T>::from_f(g2 * d);
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) {
+        dgates[row * 3] = a0;
+        dgates[row * 3 + 1] = a1;
+        dgates[row * 3 + 2] = a2;
+    }
+}
+
+int launch_gate_combine_bwd(const GateCombineParams &P, const void *dO, const float *gates, void *dOc, void *dOs, void *dOw, float *dgates,
+                            int dtype, hipStream_t st) {
+    if (P.R == 0) return NSA_OK;
+    const dim3 grid((unsigned)((P.R + 3) / 4)), block(256);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(gate_combine_bwd_kernel<float>, grid, block, 0, st, P, (const float *)dO, gates, (float *)dOc, (float *)dOs, (float *)dOw, dgates);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(gate_combine_bwd_kernel<__bf16>, grid, block, 0, st, P, (const __bf16 *)dO, gates, (__bf16 *)dOc, (__bf16 *)dOs, (__bf16 *)dOw, dgates);
+    else hipLaunchKernelGGL(gate_combine_bwd_kernel<_Float16>, grid, block, 0, st, P, (const _Float16 *)dO, gates, (_Float16 *)dOc, (_Float16 *)dOs, (_Float16 *)dOw, dgates);
+    NSA_LAUNCH_CHECK("gate_combine_bwd");
+    return NSA_OK;
 }
 
 // decode: split-KV combine of the three branches + gate + mix in one pass.  One wave per (row, head), Dv = 64 (lane = column).

@@ -44,6 +44,11 @@ int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st)
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
 int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st);
 int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st);
+int launch_rope_cache_append_bwd(const RopeAppendParams &P, int dtype, hipStream_t st);
+int launch_cmp_pool_bwd(const CmpPoolParams &P, const void *dKc, const void *dVc, void *dKr, void *dVr, int S, int n_cmp, int dtype,
+                        hipStream_t st);
 int launch_gate_combine(const GateCombineParams &P, int dtype, hipStream_t st);
+int launch_gate_combine_bwd(const GateCombineParams &P, const void *dO, const float *gates, void *dOc, void *dOs, void *dOw, float *dgates,
+                            int dtype, hipStream_t st);
 
 }  // namespace nsa

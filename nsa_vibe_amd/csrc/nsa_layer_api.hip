@@ -82,6 +82,49 @@ int nsa_gate_combine(const nsa_layer_desc *L, const void *Q, const void *O_cmp, 
     return launch_gate_combine(P, L->dtype, (hipStream_t)stream);
 }
 
+int nsa_rope_cache_append_bwd(const nsa_layer_desc *L, int B, int S, int t0, const void *dQ, const void *dK_sel, const void *dV_sel,
+                              const void *dK_win, const void *dV_win, const void *dK_raw, const void *dV_raw, void *dproj, void *stream) {
+    if (int rc = check_layer(L, "rope_cache_append_bwd")) return rc;
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && t0 >= 0, "rope_cache_append_bwd: negative size");
+    if (B == 0 || S == 0) return NSA_OK;
+    NSA_CHECK_ARG(dQ && dproj, "rope_cache_append_bwd: null pointer");
+    RopeAppendParams P{};
+    P.proj = dproj;              // written
+    P.Q_out = (void *)dQ;        // read
+    P.cache[0] = (void *)dK_sel; P.cache[1] = (void *)dV_sel; P.cache[2] = (void *)dK_win; P.cache[3] = (void *)dV_win;
+    P.cache[4] = (void *)dK_raw; P.cache[5] = (void *)dV_raw;
+    P.B = B; P.S = S; P.G = L->G; P.h = L->h; P.Dk = L->Dk; P.Dv = L->Dv; P.S_max = S; P.t0 = t0;
+    P.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
+    P.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    return launch_rope_cache_append_bwd(P, L->dtype, (hipStream_t)stream);
+}
+
+int nsa_cmp_pool_bwd(const nsa_layer_desc *L, int B, int S, int n_cmp, const void *dK_cmp, const void *dV_cmp, void *dK_raw, void *dV_raw,
+                     void *stream) {
+    if (int rc = check_layer(L, "cmp_pool_bwd")) return rc;
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && n_cmp >= 0, "cmp_pool_bwd: negative size");
+    if (B == 0 || S == 0) return NSA_OK;
+    NSA_CHECK_ARG(dK_raw && dV_raw && ((dK_cmp && dV_cmp) || n_cmp == 0), "cmp_pool_bwd: null pointer");
+    NSA_CHECK_ARG(n_cmp == 0 || (int64_t)(n_cmp - 1) * L->d + L->l <= S, "cmp_pool_bwd: windows reach past S");
+    CmpPoolParams P{};
+    P.nbg = B * L->G; P.Dk = L->Dk; P.Dv = L->Dv; P.l = L->l; P.d = L->d;
+    P.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
+    P.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    return launch_cmp_pool_bwd(P, dK_cmp, dV_cmp, dK_raw, dV_raw, S, n_cmp, L->dtype, (hipStream_t)stream);
+}
+
+int nsa_gate_combine_bwd(const nsa_layer_desc *L, const void *dO, const void *O_cmp, const void *O_sel, const void *O_win, const float *gates,
+                         void *dO_cmp, void *dO_sel, void *dO_win, float *dgates, int64_t R, void *stream) {
+    if (int rc = check_layer(L, "gate_combine_bwd")) return rc;
+    NSA_CHECK_ARG(R >= 0, "gate_combine_bwd: negative size");
+    if (R == 0) return NSA_OK;
+    NSA_CHECK_ARG(dO && O_cmp && O_sel && O_win && gates && dO_cmp && dO_sel && dO_win && dgates, "gate_combine_bwd: null pointer");
+    GateCombineParams P{};
+    P.O_cmp = O_cmp; P.O_sel = O_sel; P.O_win = O_win;
+    P.R = R; P.h = L->h; P.Dk = L->Dk; P.Dv = L->Dv;
+    return launch_gate_combine_bwd(P, dO, gates, dO_cmp, dO_sel, dO_win, dgates, L->dtype, (hipStream_t)stream);
+}
+
 // workspace: proj | Q | O_cmp | O_sel | O_win | O_mix | ranges | selection-decode scratch | band scratch
 struct DecodeWs {
     size_t proj, q, ocmp, osel, owin, omix, ranges, sel, band, band2, total, sel_bytes, band_bytes;

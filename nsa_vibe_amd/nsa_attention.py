@@ -75,6 +75,118 @@ class GateMLP(nn.Module):
         return torch.where(peaked.unsqueeze(-1), one_hot, p)
 
 
+def _gate_probs_fn(q_pooled, w1, b1, w2, b2, tau):
+    """functional form of GateMLP.forward (used to take the gate MLP's gradient in _GateCombineFn.backward)"""
+    g = F.linear(F.silu(F.linear(q_pooled, w1, b1)), w2, b2) / max(tau, 1e-6)
+    p = F.softmax(g, dim=-1)
+    top2 = torch.topk(g.detach(), k=2, dim=-1).values
+    peaked = (top2[..., 0] - top2[..., 1]) > 50.0
+    one_hot = F.one_hot(torch.argmax(g, dim=-1), 3).to(p.dtype)
+    return torch.where(peaked.unsqueeze(-1), one_hot, p)
+
+
+class _RopeAppendFn(torch.autograd.Function):
+    """fused-projection epilogue (RoPE + append into the preallocated caches) as a differentiable op: returns Q and the S
+    appended rows of the six caches (views of the cache buffers); backward = nsa_rope_cache_append_bwd."""
+
+    @staticmethod
+    def forward(ctx, proj, module, kv, S):
+        L, dev = _lib.lib(), proj.device
+        desc, _ = module._layer_desc()
+        kd = module._kv_desc(kv)
+        B = proj.shape[0]
+        proj = proj.contiguous()
+        Q = torch.empty((B, S, module.n_kv_groups, module.h_per_group, module.d_k), dtype=proj.dtype, device=dev)
+        _lib.check(L.nsa_rope_cache_append(ctypes.byref(desc), ctypes.byref(kd), proj.data_ptr(), Q.data_ptr(), S, 0, _stream(dev)),
+                   "nsa_rope_cache_append")
+        ctx.module, ctx.B, ctx.S, ctx.NT = module, B, S, proj.shape[-1]
+        return (Q, kv._K_sel[:, :, :S], kv._V_sel[:, :, :S], kv._K_win[:, :, :S], kv._V_win[:, :, :S], kv._K_raw[:, :, :S],
+                kv._V_raw[:, :, :S])
+
+    @staticmethod
+    def backward(ctx, dQ, *dcache):
+        m, B, S = ctx.module, ctx.B, ctx.S
+        L, dev = _lib.lib(), dQ.device if dQ is not None else dcache[0].device
+        desc, _ = m._layer_desc()
+        ref = dQ if dQ is not None else next(d for d in dcache if d is not None)
+        if dQ is None:
+            dQ = torch.zeros((B, S, m.n_kv_groups, m.h_per_group, m.d_k), dtype=ref.dtype, device=dev)
+        keep = [dQ.contiguous()] + [None if d is None else d.contiguous() for d in dcache]
+        dproj = torch.empty((B, S, ctx.NT), dtype=ref.dtype, device=dev)
+        ptr = [None if t is None else t.data_ptr() for t in keep]
+        _lib.check(L.nsa_rope_cache_append_bwd(ctypes.byref(desc), B, S, 0, *ptr, dproj.data_ptr(), _stream(dev)), "nsa_rope_cache_append_bwd")
+        return dproj, None, None, None
+
+
+class _CmpPoolFn(torch.autograd.Function):
+    """compressed-token pooling phi over the raw-token cache as a differentiable op (K_raw / V_raw are taken as inputs only
+    to connect the graph; the kernel reads the cache they are views of)"""
+
+    @staticmethod
+    def forward(ctx, K_raw, V_raw, module, kv, S):
+        L, dev = _lib.lib(), K_raw.device
+        desc, _ = module._layer_desc()
+        kd = module._kv_desc(kv)
+        n_cmp = 0 if S < module.l else (S - module.l) // module.d + 1
+        _lib.check(L.nsa_cmp_pool_append(ctypes.byref(desc), ctypes.byref(kd), 0, n_cmp, _stream(dev)), "nsa_cmp_pool_append")
+        kv.n_cmp = n_cmp
+        ctx.module, ctx.S, ctx.n_cmp, ctx.B = module, S, n_cmp, K_raw.shape[0]
+        return kv._K_cmp[:, :, :n_cmp], kv._V_cmp[:, :, :n_cmp]
+
+    @staticmethod
+    def backward(ctx, dKc, dVc):
+        m, S, n_cmp, B = ctx.module, ctx.S, ctx.n_cmp, ctx.B
+        ref = dKc if dKc is not None else dVc
+        L, dev = _lib.lib(), ref.device
+        desc, _ = m._layer_desc()
+        G = m.n_kv_groups
+        dKc = torch.zeros((B, G, n_cmp, m.d_k), dtype=ref.dtype, device=dev) if dKc is None else dKc.contiguous()
+        dVc = torch.zeros((B, G, n_cmp, m.d_v), dtype=ref.dtype, device=dev) if dVc is None else dVc.contiguous()
+        dKr = torch.empty((B, G, S, m.d_k), dtype=ref.dtype, device=dev)
+        dVr = torch.empty((B, G, S, m.d_v), dtype=ref.dtype, device=dev)
+        _lib.check(L.nsa_cmp_pool_bwd(ctypes.byref(desc), B, S, n_cmp, dKc.data_ptr() if n_cmp else None, dVc.data_ptr() if n_cmp else None,
+                                      dKr.data_ptr(), dVr.data_ptr(), _stream(dev)), "nsa_cmp_pool_bwd")
+        return dKr, dVr, None, None, None
+
+
+class _GateCombineFn(torch.autograd.Function):
+    """gate MLP + 3-branch combine: native forward; backward = one native pass (dO_i = gate_i dO, dgate = sum O_i dO) plus the
+    gradient of the tiny gate MLP taken with torch on the recomputed [R,Dk] -> [R,3] network"""
+
+    @staticmethod
+    def forward(ctx, Q, O_cmp, O_sel, O_win, w1, b1, w2, b2, module):
+        L, dev = _lib.lib(), Q.device
+        desc, _ = module._layer_desc()
+        Qc, Oc, Os, Ow = Q.contiguous(), O_cmp.contiguous(), O_sel.contiguous(), O_win.contiguous()
+        B, S, G = Qc.shape[:3]
+        O = torch.empty_like(Os)
+        gates = torch.empty((B, S, G, 3), dtype=torch.float32, device=dev)
+        _lib.check(L.nsa_gate_combine(ctypes.byref(desc), Qc.data_ptr(), Oc.data_ptr(), Os.data_ptr(), Ow.data_ptr(), O.data_ptr(),
+                                      gates.data_ptr(), B * S * G, _stream(dev)), "nsa_gate_combine")
+        ctx.save_for_backward(Qc, Oc, Os, Ow, gates, w1, b1, w2, b2)
+        ctx.module = module
+        module._last_gates = gates
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Qc, Oc, Os, Ow, gates, w1, b1, w2, b2 = ctx.saved_tensors
+        m = ctx.module
+        L, dev = _lib.lib(), dO.device
+        desc, _ = m._layer_desc()
+        dO = dO.contiguous()
+        dOc, dOs, dOw = torch.empty_like(Oc), torch.empty_like(Os), torch.empty_like(Ow)
+        dg = torch.empty_like(gates)
+        R = gates.numel() // 3
+        _lib.check(L.nsa_gate_combine_bwd(ctypes.byref(desc), dO.data_ptr(), Oc.data_ptr(), Os.data_ptr(), Ow.data_ptr(), gates.data_ptr(),
+                                          dOc.data_ptr(), dOs.data_ptr(), dOw.data_ptr(), dg.data_ptr(), R, _stream(dev)), "nsa_gate_combine_bwd")
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) for t in (Qc, w1, b1, w2, b2)]
+            g = _gate_probs_fn(ins[0].mean(dim=3), ins[1], ins[2], ins[3], ins[4], m.gate_temp)
+            grads = torch.autograd.grad(g, ins, dg.to(g.dtype), allow_unused=True)
+        return (grads[0], dOc, dOs, dOw, grads[1], grads[2], grads[3], grads[4], None)
+
+
 class NSAAttention(nn.Module):
     def __init__(self, dim: int, n_heads: int, n_kv_groups: int, d_k: int, d_v: int, l: int = 32, d: int = 16, l_sel: int = 64,
                  n_sel: int = 16, w: int = 512, phi: str = "avg", gate_hidden: Optional[int] = None, gate_temp: float = 1.0,
@@ -151,6 +263,11 @@ class NSAAttention(nn.Module):
             return False
         return x.is_cuda and x.dtype in _DT and self.W_Q.weight.dtype == x.dtype and self.gate.fc1.out_features <= 64
 
+    def _train_native_ok(self, x: torch.Tensor) -> bool:
+        """training (autograd) on the GPU: the layer kernels run as differentiable ops (native backward kernels)"""
+        return (torch.is_grad_enabled() and x.is_cuda and x.dtype in _DT and self.W_Q.weight.dtype == x.dtype
+                and self.gate.fc1.out_features <= 64 and os.getenv("NSA_HIP_EAGER_TRAIN", "0") != "1")
+
     def _layer_desc(self):
         """(nsa_layer_desc, fused W_qkv) -- rebuilt when a parameter was modified or moved (tensor version counters)"""
         ps = [getattr(self, n).weight for n in self._QKV] + [self.out.weight, self.gate.fc1.weight, self.gate.fc1.bias,
@@ -226,6 +343,8 @@ class NSAAttention(nn.Module):
             n_cmp = 0 if S < self.l else (S - self.l) // self.d + 1
             _lib.check(L.nsa_cmp_pool_append(ctypes.byref(desc), ctypes.byref(kd), 0, n_cmp, _stream(dev)), "nsa_cmp_pool_append")
             kv.n_cmp = n_cmp
+        elif self._train_native_ok(x):
+            return self._prefill_train_native(x, kv)
         else:
             pos = torch.arange(S, device=x.device)
             Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = self._project(x, pos)
@@ -254,6 +373,33 @@ class NSAAttention(nn.Module):
             self._last_gates = gates
             return self.out(O.reshape(B, S, self.n_heads * self.d_v)), kv
         return self._combine(Q, O_cmp, O_sel, O_win), kv
+
+    def _prefill_train_native(self, x: torch.Tensor, kv: NSA_KV):
+        """training forward: one fused projection GEMM, then every stage is a differentiable native op (the attention branches
+        with their backward kernels, RoPE/append, pooling and gate/combine with theirs)"""
+        B, S, _ = x.shape
+        if S > kv._K_sel.shape[2]:
+            raise RuntimeError(f"NSA_KV capacity exceeded: {S} > S_max={kv.S_max}")
+        W_qkv = torch.cat([getattr(self, n).weight for n in self._QKV], dim=0)
+        proj = F.linear(x, W_qkv)
+        Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = _RopeAppendFn.apply(proj, self, kv, S)
+        kv.t = S
+        K_cmp, V_cmp = _CmpPoolFn.apply(K_raw, V_raw, self, kv, S)
+        meta = kv.ensure_meta(S)
+        scale = 1.0 / math.sqrt(self.d_k)
+        with torch.no_grad():  # the selection itself is not differentiable (top-n indices)
+            p_grp = selection_scores(Q.detach(), kv.K_cmp, meta, scale, causal_skip=True)
+            if self.selector == "batched":
+                ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
+            else:
+                ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+        self._last_ranges = ranges
+        O_sel = selection_attention_hip(Q, K_sel, V_sel, ranges, scale=scale)
+        O_cmp = batched_causal_attention_compressed(Q, K_cmp, V_cmp, self.l, self.d, scale=scale)
+        O_win = sliding_window_attention(Q, K_win, V_win, self.w, scale=scale)
+        O = _GateCombineFn.apply(Q, O_cmp, O_sel, O_win, self.gate.fc1.weight, self.gate.fc1.bias, self.gate.fc2.weight, self.gate.fc2.bias,
+                                 self)
+        return self.out(O.reshape(B, S, self.n_heads * self.d_v)), kv
 
     def _decode_native(self, x: torch.Tensor, kv: NSA_KV):
         """the whole decode step in one native call (nsa_layer_decode_step): ~15 kernel launches, no host sync"""

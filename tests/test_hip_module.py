@@ -103,7 +103,7 @@ def test_module_full_gates_runs_and_is_causal():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
-def test_native_layer_path_matches_eager_ops(dtype, tol):
+def test_native_layer_path_matches_eager_ops(dtype, tol, monkeypatch):
     """inference runs the native layer kernels (fused QKV GEMM -> RoPE + cache append -> pooling -> branches -> gate/combine;
     decode = one nsa_layer_decode_step call); with autograd enabled the module runs the differentiable eager ops around the
     same attention kernels.  Both must give the same layer: learned gates, all three branches, prefill + 40 decode steps."""
@@ -116,8 +116,10 @@ def test_native_layer_path_matches_eager_ops(dtype, tol):
     outs = {}
     for mode in ("native", "eager"):
         kv = m.new_kv(B, S + n_dec, "cuda", dtype)
+        if mode == "eager":  # with autograd on, the layer kernels run as differentiable native ops unless this switch is set
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
         with torch.set_grad_enabled(mode == "eager"):
-            assert m._native_ok(x) == (mode == "native")
+            assert m._native_ok(x) == (mode == "native") and not (mode == "eager" and m._train_native_ok(x))
             o, kv = m(x[:, :S], kv, prefill=True)
             dec = []
             for t in range(S, S + n_dec):
@@ -224,7 +226,7 @@ def test_linear_small(dtype, M):
     assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
-def test_batched_decode_native_matches_eager():
+def test_batched_decode_native_matches_eager(monkeypatch):
     """B = 24 rows per step: the MFMA projection kernels and the non-split / split branch routes of the one-call decode step"""
     from nsa_vibe_amd.nsa_attention import NSAAttention
 
@@ -236,6 +238,8 @@ def test_batched_decode_native_matches_eager():
     outs = {}
     for mode in ("native", "eager"):
         kv = m.new_kv(B, S + n_dec, "cuda", dtype)
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
         with torch.set_grad_enabled(mode == "eager"):
             _, kv = m(x[:, :S], kv, prefill=True)
             dec = []
@@ -246,3 +250,33 @@ def test_batched_decode_native_matches_eager():
     err = (outs["native"] - outs["eager"]).abs().amax(dim=-1)
     assert torch.isfinite(outs["native"]).all()
     assert err.median().item() <= 6e-2 and (err <= 6e-2).float().mean().item() >= 0.9
+
+
+def test_training_native_ops_match_eager_training_bf16(monkeypatch):
+    """bf16 training step: the differentiable native layer ops (fused projection, RoPE/append, pooling, gate/combine and their
+    backward kernels) against the eager-op training path around the same attention kernels"""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    torch.manual_seed(7)
+    m = NSAAttention(256, 8, 2, 64, 64, l=32, d=16, l_sel=64, n_sel=4, w=96, selector="batched").cuda().bfloat16().train()
+    B, S = 2, 300
+    x0 = torch.randn(B, S, 256, device="cuda", dtype=torch.bfloat16)
+    go = torch.randn(B, S, 256, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    for mode in ("native", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        x = x0.clone().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        assert m._train_native_ok(x) == (mode == "native")
+        out, _ = m(x, m.new_kv(B, S, "cuda", torch.bfloat16), prefill=True)
+        out.backward(go)
+        res[mode] = (out.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
+    on, oe = res["native"][0], res["eager"][0]
+    assert (on - oe).abs().amax(dim=-1).median().item() <= 6e-2
+    gn, ge = res["native"][1], res["eager"][1]
+    assert (gn - ge).abs().mean().item() <= 0.05 * ge.abs().mean().item() + 1e-3
+    for n in res["eager"][2]:
+        a, b = res["native"][2][n], res["eager"][2][n]
+        assert torch.isfinite(a).all(), n
+        assert (a - b).abs().mean().item() <= 0.08 * b.abs().mean().item() + 2e-3, n
