@@ -57,20 +57,24 @@ __device__ __forceinline__ uint32_t off_tr_img(int r, int piece) {
 }
 
 // ------------------------------------------------------------------------------------------ 1. delta
+// Dv = 64: 8 lanes per (row, head), 16 bytes per lane -- a wave reads 8 whole rows of O and of dO per instruction (one thread
+// per row made every lane walk its own 128-byte row: 0.9 TB/s)
 template <typename T>
 __global__ __launch_bounds__(256) void bwd_delta_kernel(const T *__restrict__ O, const T *__restrict__ dO, float *__restrict__ delta,
                                                          int64_t n_rows, int Dv) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_rows) return;
-    const T *o = O + i * Dv, *g = dO + i * Dv;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;  // (row, head)
+    const int sub = threadIdx.x & 7;
     float acc = 0.f;
-    for (int e = 0; e < Dv; e += 8) {
-        const u32x4 a = *(const u32x4 *)(o + e), b = *(const u32x4 *)(g + e);
+    if (i < n_rows) {
+        const u32x4 a = *(const u32x4 *)(O + i * Dv + 8 * sub), b = *(const u32x4 *)(dO + i * Dv + 8 * sub);
         const T *pa = (const T *)&a, *pb = (const T *)&b;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc = fmaf(Elt<T>::to_f(pa[k]), Elt<T>::to_f(pb[k]), acc);
     }
-    delta[i] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (i < n_rows && sub == 0) delta[i] = acc;
 }
 
 // ------------------------------------------------------------------------------------------ 2. dQ (query-major)
@@ -589,7 +593,7 @@ size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_k
 template <typename T>
 static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st) {
     const int64_t nrh = P.R * P.h;
-    hipLaunchKernelGGL(bwd_delta_kernel<T>, dim3((unsigned)((nrh + 255) / 256)), dim3(256), 0, st, (const T *)P.O, (const T *)P.dO, delta,
+    hipLaunchKernelGGL(bwd_delta_kernel<T>, dim3((unsigned)((nrh * 8 + 255) / 256)), dim3(256), 0, st, (const T *)P.O, (const T *)P.dO, delta,
                        nrh, P.Dv);
     NSA_LAUNCH_CHECK("bwd_delta");
     int map_mode = 0;
