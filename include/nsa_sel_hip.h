@@ -118,6 +118,16 @@ NSA_API int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void 
                       int64_t v_stride_b, int64_t v_stride_g, int64_t v_stride_s, int t0, int a, int dd, int c, int w,
                       int dtype, float scale, int variant, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Band attention backward (same interval rule and layouts as nsa_band_attn_fwd; O and lse from the forward; dQ in the activation
+ * dtype, dK/dV fp32 [B,G,S_kv,D] fully written).  MFMA route (bf16/f16, Dk = Dv = 64): dQ by a dense 48-slot query-major kernel, dK/dV by
+ * the key-block-major kernels of nsa_sel_attn_bwd fed with one [lo,hi) range per row; otherwise the generic selection backward. */
+NSA_API size_t nsa_band_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant);
+NSA_API int nsa_band_attn_bwd(const void *Q, const void *K, const void *V, const void *O, const float *lse, const void *dO, void *dQ,
+                      float *dK, float *dV, int B, int S, int G, int h, int Dk, int Dv, int S_kv, int64_t k_stride_b,
+                      int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b, int64_t v_stride_g, int64_t v_stride_s, int t0,
+                      int a, int dd, int c, int w, int dtype, float scale, int variant, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Layer-level entry points: NSAAttention around the three branches (nsa/core/nsa_attention.py).  Plain-C descriptors:
  *   nsa_layer_desc  geometry + weights of one NSAAttention module (state-dict tensors, row-major [out,in] like nn.Linear;

@@ -55,6 +55,8 @@ SIGNATURES = {
     "nsa_gate_combine_bwd": (_i, [_pl] + [_vp] * 9 + [_i64, _vp]),
     "nsa_layer_decode_step_workspace": (_sz, [_pl, _i, _i]),
     "nsa_layer_decode_step": (_i, [_pl, _pk, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "nsa_band_attn_bwd_workspace": (_sz, [_i] * 9),
+    "nsa_band_attn_bwd": (_i, [_vp] * 9 + [_i] * 7 + [_i64] * 6 + [_i] * 5 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_block_counts": (_i, [_i] * 4 + [C.POINTER(_i)] * 3),
     "nsa_build_block_meta_host": (_i, [_i] * 4 + [_vp] * 6),
     "nsa_map_pcmp_to_pgrp": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

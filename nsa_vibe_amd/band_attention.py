@@ -9,8 +9,8 @@ row 0 (0 for prefill; a decode step passes S = 1 and t0 = position of the new to
 the decode calls of nsa_attention.py:674-703.  The compressed branch uses the true softmax over the emitted tokens
 -- the reference's per-token SDPA call (is_causal=True with one query, :139-141) attends key 0 only, a quirk that
 is deliberately not reproduced.
-Both are one C-ABI call (nsa_band_attn_fwd); the backward reuses the selection backward kernels with the band written
-as one [lo, hi) range per row.
+Both are one C-ABI call (nsa_band_attn_fwd); the backward (nsa_band_attn_bwd) takes dQ with a dense query-major kernel and
+dK/dV with the key-block-major selection backward kernels (the band written as one [lo, hi) range per row).
 """
 from __future__ import annotations
 
@@ -78,21 +78,20 @@ class _BandAttnFn(torch.autograd.Function):
         B, S, G, h, Dk = Qc.shape
         S_kv, Dv = Kc.shape[2], Vc.shape[3]
         t0, a, dd, c, w = ctx.band
-        # the band as one range per row: the selection backward kernels then do the rest
-        rg = band_ranges(S, S_kv, t0, a, dd, c, min(w, _W_INF), dev).view(1, S, 1, 1, 2).expand(B, S, G, 1, 2).contiguous()
         dO = dO.contiguous()
         dQ = torch.empty_like(Qc)
         dK = torch.empty((B, G, S_kv, Dk), dtype=torch.float32, device=dev)
         dV = torch.empty((B, G, S_kv, Dv), dtype=torch.float32, device=dev)
         L = _lib.lib()
         dt = _DT[Qc.dtype]
-        ws = workspace(dev, L.nsa_sel_attn_bwd_workspace(B, S, G, h, Dk, Dv, S_kv, dt, ctx.bwd_variant), "attn_bwd")
-        rc = L.nsa_sel_attn_bwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(), lse.data_ptr(),
-                                dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), B, S, G, h, Dk, Dv, S_kv, 1,
-                                Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
-                                dt, float(ctx.scale) if ctx.scale else 0.0, int(ctx.bwd_variant),
-                                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
-        _lib.check(rc, "nsa_sel_attn_bwd")
+        ws = workspace(dev, L.nsa_band_attn_bwd_workspace(B, S, G, h, Dk, Dv, S_kv, dt, ctx.bwd_variant) + 256, "band_bwd")
+        wptr = (ws.data_ptr() + 255) & ~255
+        rc = L.nsa_band_attn_bwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), O.data_ptr(), lse.data_ptr(), dO.data_ptr(), dQ.data_ptr(),
+                                 dK.data_ptr(), dV.data_ptr(), B, S, G, h, Dk, Dv, S_kv,
+                                 Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
+                                 int(t0), int(a), int(dd), int(c), int(min(w, _W_INF)), dt, float(ctx.scale) if ctx.scale else 0.0,
+                                 int(ctx.bwd_variant), wptr, ws.numel() - (wptr - ws.data_ptr()), _stream(dev))
+        _lib.check(rc, "nsa_band_attn_bwd")
         return dQ, dK.to(Kc.dtype), dV.to(Vc.dtype), None, None, None
 
 

@@ -248,6 +248,60 @@ int nsa_band_attn_fwd(const void *Q, const void *K, const void *V, void *O, floa
                               workspace, workspace_bytes, stream, 0, nullptr);
 }
 
+// Band attention backward.  dQ: dense 48-slot kernel (MFMA route); dK/dV: the key-block-major selection backward kernels fed
+// with the band as one range per row.  workspace = selection-backward workspace (its delta area is shared) + the ranges.
+static size_t band_bwd_ranges_off(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant) {
+    return (nsa_sel_attn_bwd_workspace(B, S, G, h, Dk, Dv, S_kv, dtype, variant) + 255) & ~(size_t)255;
+}
+
+size_t nsa_band_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant) {
+    return band_bwd_ranges_off(B, S, G, h, Dk, Dv, S_kv, dtype, variant) + sizeof(int32_t) * 2 * (size_t)B * S * G;
+}
+
+int nsa_band_attn_bwd(const void *Q, const void *K, const void *V, const void *O, const float *lse, const void *dO, void *dQ, float *dK,
+                      float *dV, int B, int S, int G, int h, int Dk, int Dv, int S_kv, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
+                      int64_t vsg, int64_t vss, int t0, int a, int dd, int c, int w, int dtype, float scale, int variant, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "band_attn_bwd: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0, "band_attn_bwd: negative size");
+    NSA_CHECK_ARG(t0 >= 0 && dd >= 1 && w >= 0, "band_attn_bwd: need t0 >= 0, dd >= 1, w >= 0");
+    NSA_CHECK_ARG(variant >= 0 && variant <= 2, "band_attn_bwd: unknown variant %d", variant);
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t roff = band_bwd_ranges_off(B, S, G, h, Dk, Dv, S_kv, dtype, variant);
+    NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 256 == 0) && workspace_bytes >= roff + sizeof(int32_t) * 2 * (size_t)R,
+                  "band_attn_bwd: workspace missing, misaligned or too small");
+    int32_t *ranges = (int32_t *)((unsigned char *)workspace + roff);
+    if (int rc = launch_band_ranges(ranges, B, S, G, S_kv, t0, a, dd, c, w, st)) return rc;
+    const bool fast_ok = S_kv > 0 && w > 0 && roff > 0 && band_attn_mfma_supported(dtype, h, Dk, Dv) && sel_attn_bwd_mfma_supported(dtype, h, Dk, Dv) &&
+                         kss % 8 == 0 && vss % 8 == 0 && ksb % 8 == 0 && vsb % 8 == 0 && ksg % 8 == 0 && vsg % 8 == 0 &&
+                         ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)dO % 16 == 0) &&
+                         ((uintptr_t)O % 16 == 0) && (int64_t)B * G <= 65535 && (int64_t)S_kv * kss * 2 < ((int64_t)1 << 31) &&
+                         (int64_t)S_kv * vss * 2 < ((int64_t)1 << 31);
+    if (variant == 2) NSA_CHECK_ARG(fast_ok, "band_attn_bwd: MFMA variant requested but shape/dtype/alignment unsupported");
+    if (!fast_ok || variant == 1)
+        return nsa_sel_attn_bwd(Q, K, V, ranges, O, lse, dO, dQ, dK, dV, B, S, G, h, Dk, Dv, S_kv, 1, ksb, ksg, kss, vsb, vsg, vss, dtype, scale,
+                                variant == 2 ? 0 : variant, workspace, roff, stream);
+    NSA_CHECK_ARG(Q && K && V && O && lse && dO && dQ && dK && dV, "band_attn_bwd: null pointer");
+    float *delta = (float *)workspace;
+    if (int rc = launch_bwd_delta(O, dO, delta, R * h, Dv, dtype, st)) return rc;
+    BandAttnParams BP{};
+    BP.Q = Q; BP.K = K; BP.V = V;
+    BP.B = B; BP.S = S; BP.G = G; BP.h = h; BP.Dk = Dk; BP.Dv = Dv; BP.S_kv = S_kv;
+    BP.ksb = ksb; BP.ksg = ksg; BP.kss = kss; BP.vsb = vsb; BP.vsg = vsg; BP.vss = vss;
+    BP.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    BP.t0 = t0; BP.a = a; BP.dd = dd; BP.c = c; BP.w = w;
+    if (int rc = launch_band_attn_bwd_dq(BP, dO, lse, delta, dQ, dtype, st)) return rc;
+    SelAttnBwdParams P{};
+    P.Q = Q; P.K = K; P.V = V; P.ranges = ranges; P.O = O; P.lse = lse; P.dO = dO; P.dQ = dQ; P.dK = dK; P.dV = dV;
+    P.R = R; P.S = S; P.G = G; P.h = h; P.Dk = Dk; P.Dv = Dv; P.S_kv = S_kv; P.n = 1;
+    P.ksb = ksb; P.ksg = ksg; P.kss = kss; P.vsb = vsb; P.vsg = vsg; P.vss = vss;
+    P.scale = BP.scale;
+    P.skip_delta_dq = 1;
+    return launch_sel_attn_bwd_mfma(P, dtype, delta, st);
+}
+
 // ------------------------------------------------------------------------------ block meta (host)
 int nsa_block_counts(int seq_len, int l, int d, int l_sel, int *S_cmp, int *S_sel, int *nnz) {
     NSA_CHECK_ARG(l > 0 && d > 0 && l_sel > 0, "Block parameters must be positive");

@@ -593,9 +593,11 @@ size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_k
 template <typename T>
 static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st) {
     const int64_t nrh = P.R * P.h;
-    hipLaunchKernelGGL(bwd_delta_kernel<T>, dim3((unsigned)((nrh * 8 + 255) / 256)), dim3(256), 0, st, (const T *)P.O, (const T *)P.dO, delta,
-                       nrh, P.Dv);
-    NSA_LAUNCH_CHECK("bwd_delta");
+    if (!P.skip_delta_dq) {
+        hipLaunchKernelGGL(bwd_delta_kernel<T>, dim3((unsigned)((nrh * 8 + 255) / 256)), dim3(256), 0, st, (const T *)P.O, (const T *)P.dO,
+                           delta, nrh, P.Dv);
+        NSA_LAUNCH_CHECK("bwd_delta");
+    }
     int map_mode = 0;
     unsigned grid = (unsigned)((P.R + 3) / 4);
     if (P.S >= 16) {
@@ -606,8 +608,10 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
         }
     }
     constexpr size_t lds = 4 * (3 * 32 * BROWB + ((SEG_INTS * 4 + 15) / 16) * 16);
-    hipLaunchKernelGGL(bwd_dq_kernel<T>, dim3(grid), dim3(256), lds, st, P, (const float *)delta, map_mode);
-    NSA_LAUNCH_CHECK("bwd_dq");
+    if (!P.skip_delta_dq) {
+        hipLaunchKernelGGL(bwd_dq_kernel<T>, dim3(grid), dim3(256), lds, st, P, (const float *)delta, map_mode);
+        NSA_LAUNCH_CHECK("bwd_dq");
+    }
     const int64_t nbg = (int64_t)(P.R / P.S);
     NSA_CHECK_ARG(nbg <= 65535, "bwd: B*G too large for one launch");
     const BwdWs W = bwd_ws_layout(P.R, P.h, P.S, nbg, P.S_kv);
@@ -649,6 +653,34 @@ int launch_sel_attn_bwd_mfma(const SelAttnBwdParams &P, int dtype, float *delta_
                   "bwd MFMA: one (b,g) K/V slab must be smaller than 2 GiB");
     if (dtype == NSA_DT_BF16) return launch_bwd_t<__bf16>(P, delta_ws, st);
     return launch_bwd_t<_Float16>(P, delta_ws, st);
+}
+
+int launch_bwd_delta(const void *O, const void *dO, float *delta, int64_t n_rows, int Dv, int dtype, hipStream_t st) {
+    NSA_CHECK_ARG(Dv == 64 && (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16), "bwd_delta: bf16/f16 with Dv = 64 only");
+    const dim3 grid((unsigned)((n_rows * 8 + 255) / 256));
+    if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(bwd_delta_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)O, (const __bf16 *)dO, delta, n_rows, Dv);
+    else hipLaunchKernelGGL(bwd_delta_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16 *)O, (const _Float16 *)dO, delta, n_rows, Dv);
+    NSA_LAUNCH_CHECK("bwd_delta");
+    return NSA_OK;
+}
+
+// the band as one [lo, hi) range per (b,t,g) row: input of the selection backward kernels
+__global__ __launch_bounds__(256) void band_ranges_kernel(int32_t *__restrict__ ranges, int64_t R, int S, int G, int S_kv, int t0, int a, int dd,
+                                                          int c, int w) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= R) return;
+    const int t = (int)((row / G) % S);
+    const int hi = band_hi(t0, a, dd, c, S_kv, t);
+    ranges[2 * row] = max(0, hi - w);
+    ranges[2 * row + 1] = hi;
+}
+
+int launch_band_ranges(int32_t *ranges, int B, int S, int G, int S_kv, int t0, int a, int dd, int c, int w, hipStream_t st) {
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    hipLaunchKernelGGL(band_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, ranges, R, S, G, S_kv, t0, a, dd, c, w);
+    NSA_LAUNCH_CHECK("band_ranges");
+    return NSA_OK;
 }
 
 }  // namespace nsa

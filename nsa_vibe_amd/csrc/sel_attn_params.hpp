@@ -35,6 +35,7 @@ struct SelAttnBwdParams {
     int S, G, h, Dk, Dv, S_kv, n;
     int64_t ksb, ksg, kss, vsb, vsg, vss;
     float scale;
+    int skip_delta_dq;  // MFMA route: delta is already in the workspace and dQ is produced elsewhere (band backward)
 };
 
 // Band attention (sliding-window and compressed branches): query row t (position t0 + t) attends keys [max(0, hi - w), hi),
@@ -66,6 +67,10 @@ bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
 size_t band_attn_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int *nsplit_out);
 int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st);
 int launch_band_attn_fwd_dual(const BandAttnParams &P0, const BandAttnParams &P1, int dtype, hipStream_t st);
+int launch_band_attn_bwd_dq(const BandAttnParams &P, const void *dO, const float *lse, const float *delta, void *dQ, int dtype,
+                            hipStream_t st);
+int launch_bwd_delta(const void *O, const void *dO, float *delta, int64_t n_rows, int Dv, int dtype, hipStream_t st);
+int launch_band_ranges(int32_t *ranges, int B, int S, int G, int S_kv, int t0, int a, int dd, int c, int w, hipStream_t st);
 int launch_band_attn_fwd_generic(const BandAttnParams &P, int dtype, hipStream_t st);
 
 int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);

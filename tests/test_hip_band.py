@@ -145,3 +145,23 @@ def test_backward_vs_oracle(nv, orc, band):
     for got, ref, name in ((q.grad, rq, "dQ"), (k.grad, rk, "dK"), (v.grad, rv, "dV")):
         err = np.abs(got.float().cpu().numpy() - ref).max()
         assert err <= 2e-2 * max(1.0, np.abs(ref).max()), f"{name}: {err:.3e}"
+
+
+@pytest.mark.parametrize("band,B,S,G", [(dict(w=512), 2, 2100, 4), (dict(a=32, dd=16, c=1), 2, 2100, 4), (dict(w=100), 1, 777, 3)])
+def test_backward_dense_dq_kernel_vs_oracle(nv, orc, band, B, S, G):
+    """the 48-slot dQ kernel (>= 2048 token groups) and its 16-slot variant, m7c head geometry"""
+    from nsa_vibe_amd.band_attention import band_attention_hip
+
+    h = 6
+    S_kv = S if "w" in band else (S - 32) // 16 + 1
+    Q, K, V = rand_qkv(1900 + S, B, S, G, h, 64, 64, S_kv)
+    dO = np.random.default_rng(1901).standard_normal((B, S, G, h, 64), dtype=np.float32)
+    dt = torch.bfloat16
+    q, k, v = (dev(x, dt).requires_grad_(True) for x in (Q, K, V))
+    band_attention_hip(q, k, v, variant=2, **band).backward(dev(dO, dt))
+    rq, rk, rv = orc.band_attention_bwd(rounded(Q, dt), rounded(K, dt), rounded(V, dt), rounded(dO, dt), **band)
+    for got, ref, name in ((q.grad, rq, "dQ"), (k.grad, rk, "dK"), (v.grad, rv, "dV")):
+        g = got.float().cpu().numpy()
+        assert np.isfinite(g).all(), name
+        err = np.abs(g - ref).max()
+        assert err <= 2e-2 * max(1.0, np.abs(ref).max()), f"{name}: {err:.3e}"
