@@ -170,15 +170,15 @@ def layer_bench(nv, B, S, device, steps=40):
 
 
 def layer_train_bench(nv, B, S, device, iters=5):
-    """forward + backward of the NSAAttention layer with autograd (config 5 shape): the attention branches run the HIP
-    forward/backward kernels, projections / RoPE / gate are eager differentiable torch ops"""
+    """forward + backward of the NSAAttention layer with autograd (config 5 shape): fused projection GEMM, then every stage
+    (RoPE/append, pooling, the three attention branches, gate/combine) is a differentiable native op with its backward kernel"""
     torch.manual_seed(0)
     m = nv.NSAAttention(768, 12, G, D, D, L_CMP, D_CMP, L_SEL, N_SEL, 512, selector="batched").to(device).to(torch.bfloat16).train()
     x = torch.randn(B, S, 768, device=device, dtype=torch.bfloat16, requires_grad=True)
     go = torch.randn(B, S, 768, device=device, dtype=torch.bfloat16)
     a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    tf = tb = 0.0
-    for i in range(iters + 2):
+    tfs, tbs = [], []
+    for i in range(iters + 3):
         m.zero_grad(set_to_none=True)
         x.grad = None
         kv = m.new_kv(B, S, device, torch.bfloat16)
@@ -188,9 +188,10 @@ def layer_train_bench(nv, B, S, device, iters=5):
         out.backward(go)
         c.record()
         torch.cuda.synchronize()
-        if i >= 2:
-            tf += a.elapsed_time(b) / iters
-            tb += b.elapsed_time(c) / iters
+        if i >= 3:
+            tfs.append(a.elapsed_time(b))
+            tbs.append(b.elapsed_time(c))
+    tf, tb = float(np.median(tfs)), float(np.median(tbs))
     return {"fwd_ms": tf, "bwd_ms": tb, "tok_per_s": B * S / ((tf + tb) * 1e-3)}
 
 
