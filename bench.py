@@ -5,6 +5,7 @@
 
 A "step" = one pass of the hot path over one batch of synthetic input for one layer:
     Q,K_cmp -> p_grp (softmax scores, Eq.9, Eq.10) -> deterministic top-n ranges -> selection attention
+(two launches: the fused scorer, then one kernel that selects the row's ranges and attends over them)
 on the m7c_125m shape (dim 768: 12 heads, G=2, h=6, d_k=d_v=64; l=32 d=16 l'=64 n=16), S=4096, bf16,
 B sequences per GPU (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.
 Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequences, no data-path
@@ -52,9 +53,9 @@ def make_inputs(nv, B, S, device, seed):
 def hot_path(nv, meta, Q, Kc, K, V, S):
     # causal_skip: scores of blocks that both selectors mask to -inf at row t are not computed
     p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True)
-    ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
-    O = nv.selection_attention_hip(Q, K, V, ranges)
-    return ranges, O
+    # batched top-n (select_topn_ranges_batched semantics) + selection attention: one native call, the selector runs inside the
+    # attention launch; the ranges are still materialised (they are an output of the path)
+    return nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched")
 
 
 def time_events(fn, iters, warm=2):
@@ -72,11 +73,13 @@ def time_events(fn, iters, warm=2):
 
 
 def stage_times(nv, meta, Q, Kc, K, V, S, iters):
+    """per-stage HIP-event times.  The step runs scores, then ONE launch that selects and attends (the selector runs inside the
+    attention kernel): that launch is the dominant kernel of the roofline; the standalone select kernel is timed for reference."""
     p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True)
     ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
     t_sc = time_events(lambda: nv.selection_scores(Q, Kc, meta, causal_skip=True), iters)
     t_sel = time_events(lambda: nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S), iters)
-    t_att = time_events(lambda: nv.selection_attention_hip(Q, K, V, ranges), iters)
+    t_att = time_events(lambda: nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched"), iters)
     L = (ranges[..., 1] - ranges[..., 0]).clamp_min(0).sum(-1).double()
     return t_sc, t_sel, t_att, float(L.sum().item()), float(L.mean().item())
 
@@ -319,7 +322,7 @@ def main():
                                       "runs against the aggregate L2 bandwidth, not HBM",
                            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
                            "mfma_tflops": flops / (t_att * 1e-3) / 1e12, "mfma_frac": flops / (t_att * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-        out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att}
+        out["stages_ms"] = {"scores": t_sc, "select_and_attention_one_launch": t_att, "select_standalone_kernel": t_sel}
         if not args.no_extra and world == 1:
             extra = {}
             try:
@@ -330,7 +333,7 @@ def main():
                     m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
                     ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 3, warm=1)
                     sc, se, at, Ls, Lm = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 3)
-                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "scores_ms": sc, "select_ms": se, "attention_ms": at,
+                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "scores_ms": sc, "select_standalone_ms": se, "select_and_attention_ms": at,
                                                     "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9, "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12}
                     del m2, Q2, Kc2, K2, V2
                 # next scope rows: backward, the sliding/compressed branch kernel (MFMA bound), the whole layer on the native path

@@ -246,6 +246,18 @@ NSA_API int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, 
                            int32_t *ranges_out, int out_width, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Top-n selection + selection attention in one call (prefill): the arguments of nsa_select_topn_ranges followed by those of
+ * nsa_sel_attn_fwd; ranges_out [B,S,G,out_width,2] is produced AND consumed.  On the MFMA route with enough rows the selection
+ * runs inside the attention kernel (one launch); otherwise the two kernels are launched back to back.  Results are those
+ * of the two separate calls, bit for bit.
+ * ------------------------------------------------------------------------------------- */
+NSA_API int nsa_sel_select_attn_fwd(const float *p_grp, int t0, const int32_t *t_rows, int S_sel, int l_sel, int n_top, int force_init,
+                            int force_local, int mode, int S_total, int32_t *ranges_out, int out_width, const void *Q, const void *K,
+                            const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk, int Dv, int S_kv,
+                            int64_t k_stride_b, int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b, int64_t v_stride_g,
+                            int64_t v_stride_s, int dtype, float scale, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * One decode step of the selected branch in ONE call (host launch overhead matters at batch 1):
  *   Q [B,1,G,h,Dk] -> decode-shaped scores -> sequential top-n ranges at token t_token -> selection attention over
  *   K/V[:, :, :S_kv].  Replaces the calls of the decode branch of NSAAttention.forward

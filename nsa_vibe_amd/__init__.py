@@ -15,6 +15,7 @@ from .block_index import BlockMeta, build_block_meta, build_block_starts, build_
 from .selection_attention import (  # noqa: F401
     grouped_selection_attention_masked,
     hip_sel_available,
+    select_and_attend,
     selection_attention_hip,
     selection_decode_step,
 )

@@ -67,6 +67,7 @@ SIGNATURES = {
     "nsa_sel_decode_step": (_i, [_vp] * 9 + [_i] * 13 + [_i64] * 9 + [_i, _f, _vp, _sz, _vp]),
     "nsa_batched_ranges_width": (_i, [_i] * 6),
     "nsa_select_topn_ranges": (_i, [_vp, _i64, _i, _i, _i, _vp] + [_i] * 7 + [_vp, _i, _vp]),
+    "nsa_sel_select_attn_fwd": (_i, [_vp, _i, _vp] + [_i] * 7 + [_vp, _i] + [_vp] * 5 + [_i] * 7 + [_i64] * 6 + [_i, _f, _vp, _sz, _vp]),
     "nsa_indices_to_ranges_v2": (_i, [_vp, _i64] + [_i] * 6 + [_vp, _vp]),
 }
 

@@ -10,6 +10,7 @@
 #include "nsa_common.hpp"
 #include "sel_attn_params.hpp"
 #include "nsa_internal.hpp"
+#include "sel_select_row.hpp"
 
 namespace nsa {
 
@@ -450,6 +451,43 @@ int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, int t0, 
     NSA_CHECK_ARG(p_grp && ranges_out || R == 0, "select_topn_ranges: null pointer");
     return launch_select_topn(p_grp, R, S, G, t0, t_rows, S_sel, l_sel, n_top, force_init, force_local, mode, S_total,
                               ranges_out, out_width, (hipStream_t)stream);
+}
+
+int nsa_sel_select_attn_fwd(const float *p_grp, int t0, const int32_t *t_rows, int S_sel, int l_sel, int n_top, int force_init,
+                            int force_local, int mode, int S_total, int32_t *ranges_out, int out_width, const void *Q, const void *K,
+                            const void *V, void *O, float *lse, int B, int S, int G, int h, int Dk, int Dv, int S_kv, int64_t ksb,
+                            int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_select_attn_fwd: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 1 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0 && out_width >= 0, "sel_select_attn_fwd: bad sizes");
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    NSA_CHECK_ARG(p_grp && ranges_out, "sel_select_attn_fwd: null pointer");
+    int ns = 1;
+    const bool fast_ok = sel_attn_mfma_supported(dtype, h, Dk, Dv) && kss % 8 == 0 && vss % 8 == 0 && ksb % 8 == 0 && vsb % 8 == 0 &&
+                         ksg % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
+                         S_kv > 0 && out_width >= 1 && out_width <= 64 && S_sel >= 1 && S_sel <= 1024 &&
+                         (sel_attn_mfma_workspace(R, h, Dv, &ns), ns == 1);
+    if (!fast_ok) {  // two launches
+        if (int rc = nsa_select_topn_ranges(p_grp, R, S, G, t0, t_rows, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, ranges_out,
+                                            out_width, stream))
+            return rc;
+        return nsa_sel_attn_fwd(Q, K, V, ranges_out, O, lse, B, S, G, h, Dk, Dv, S_kv, out_width, ksb, ksg, kss, vsb, vsg, vss, dtype, scale, 0,
+                                workspace, workspace_bytes, stream);
+    }
+    NSA_CHECK_ARG(Q && K && V && O, "sel_select_attn_fwd: null pointer");
+    SelectParams SP{};
+    SP.p_grp = p_grp; SP.t_rows = t_rows; SP.out = ranges_out; SP.R = R; SP.S = S; SP.G = G; SP.t0 = t0;
+    if (int rc = select_params_fill(&SP, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, out_width)) return rc;
+    SelAttnParams P{};
+    P.Q = Q; P.K = K; P.V = V; P.ranges = ranges_out; P.O = O; P.lse = lse; P.R = R;
+    P.S = S; P.G = G; P.h = h; P.Dk = Dk; P.Dv = Dv; P.S_kv = S_kv; P.n = out_width;
+    P.ksb = ksb; P.ksg = ksg; P.kss = kss; P.vsb = vsb; P.vsg = vsg; P.vss = vss;
+    P.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    P.part = nullptr; P.nsplit = 1;
+    P.fuse_select = 1;
+    P.select = &SP;
+    return launch_sel_attn_fwd_mfma(P, dtype, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------ fused decode step

@@ -104,15 +104,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Returns the total number of selected tokens L (wave uniform); *nseg_out = number of segments
 // (including empty ones; empty segments have equal consecutive prefix offsets).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int normalise_ranges(const int32_t *__restrict__ rg, int n, int S_kv, int *seg,
-                                                int *nseg_out) {
+// core: lane i < n holds range i as (s, e) (unclamped)
+__device__ __forceinline__ int normalise_ranges_lanes(int s, int e, int n, int S_kv, int *seg, int *nseg_out) {
     const int lane = lane_id();
-    int s = 0, e = 0;
     if (lane < n) {
-        s = rg[2 * lane];
-        e = rg[2 * lane + 1];
         s = min(max(s, 0), S_kv);
         e = min(max(e, 0), S_kv);
+    } else {
+        s = 0;
+        e = 0;
     }
     const bool valid = e > s;
     // rank sort by (start, lane) among valid entries
@@ -165,6 +165,15 @@ __device__ __forceinline__ int normalise_ranges(const int32_t *__restrict__ rg, 
     wave_lds_fence();
     *nseg_out = nvalid;
     return total;
+}
+__device__ __forceinline__ int normalise_ranges(const int32_t *__restrict__ rg, int n, int S_kv, int *seg, int *nseg_out) {
+    const int lane = lane_id();
+    int s = 0, e = 0;
+    if (lane < n) {
+        s = rg[2 * lane];
+        e = rg[2 * lane + 1];
+    }
+    return normalise_ranges_lanes(s, e, n, S_kv, seg, nseg_out);
 }
 constexpr int SEG_INTS = 132;  // LDS ints needed by normalise_ranges per wave (>= 2*64+2, and 128 scratch)
 

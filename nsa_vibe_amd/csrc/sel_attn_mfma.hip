@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "attn_mfma_tiles.hpp"
+#include "sel_select_row.hpp"
 
 namespace nsa {
 
@@ -35,7 +36,7 @@ namespace nsa {
 // STAGE 1: tiles are written into LDS by LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR / ds_write on the path); the
 //          XOR swizzle is applied on the per-lane SOURCE offset because the DMA destination is lane-linear.
 template <typename T, int D, bool SPLIT, int STAGE>
-__global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P) {
+__global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     using M = MfmaT<T>;
     using G_ = Geo<D>;
     using x8 = typename M::x8;
@@ -80,8 +81,30 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P)
     const T *Qr = (const T *)P.Q + row * (int64_t)h * D;
     const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;  // row pitch in bytes
 
-    int nseg;
-    const int L = normalise_ranges(P.ranges + row * (int64_t)P.n * 2, P.n, P.S_kv, seg, &nseg);
+    int nseg, L;
+    if (!SPLIT && P.fuse_select) {
+        // top-n selection of this row from its group scores, in the attention kernel itself: the selector is VALU work of a
+        // few hundred instructions per row, the attention is bound by the L2 gather -- run inside this launch it costs little
+        // and the separate select kernel (8 % of the hot-path step) disappears.  Same arithmetic as select_topn_kernel.
+        const int t = SP.t_rows ? SP.t_rows[row] : SP.t0 + (int)((row / P.G) % P.S);
+        const float *pg = SP.p_grp + row * (int64_t)SP.S_sel;
+        int ms = 0, me = 0;
+        switch (cand) {
+            case 1: select_topn_row_regs<1>(SP, pg, t, ms, me); break;
+            case 2: select_topn_row_regs<2>(SP, pg, t, ms, me); break;
+            case 4: select_topn_row_regs<4>(SP, pg, t, ms, me); break;
+            case 8: select_topn_row_regs<8>(SP, pg, t, ms, me); break;
+            default: select_topn_row_regs<16>(SP, pg, t, ms, me); break;
+        }
+        if (lane < SP.W) {
+            int32_t *out = SP.out + row * (int64_t)SP.W * 2;
+            out[2 * lane] = ms;
+            out[2 * lane + 1] = me;
+        }
+        L = normalise_ranges_lanes(ms, me, SP.W, P.S_kv, seg, &nseg);
+    } else {
+        L = normalise_ranges(P.ranges + row * (int64_t)P.n * 2, P.n, P.S_kv, seg, &nseg);
+    }
 
     const int rho = lane & 15;  // MFMA row/col index of this lane
     const int q = lane >> 4;    // k-chunk group of this lane
@@ -410,13 +433,22 @@ static int launch_mfma_t(const SelAttnParams &P0, hipStream_t st) {
     }
     const char *se = getenv("NSA_HIP_ATTN_STAGE");  // A/B switch: 0 = register staging, 1 = LDS-DMA
     const int stage = se ? atoi(se) : 1;  // default: LDS-DMA (measured 3-5 % faster than register staging at S<=16k)
-    void (*k)(SelAttnParams) = nullptr;
+    void (*k)(SelAttnParams, SelectParams, int) = nullptr;
     if (split && stage == 1) k = sel_attn_fwd_mfma_kernel<T, D, true, 1>;
     else if (split) k = sel_attn_fwd_mfma_kernel<T, D, true, 0>;
     else if (stage == 1) k = sel_attn_fwd_mfma_kernel<T, D, false, 1>;
     else k = sel_attn_fwd_mfma_kernel<T, D, false, 0>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, P);
+    SelectParams SP{};
+    int cand = 0;
+    if (P.fuse_select) {
+        NSA_CHECK_ARG(!split && P.select != nullptr, "fused selection needs the non-split route");
+        SP = *(const SelectParams *)P.select;
+        const int c = (SP.S_sel + 63) / 64;
+        NSA_CHECK_ARG(c <= 16 && SP.W <= 64, "fused selection: S_sel <= 1024 and at most 64 ranges per row");
+        cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_fwd_mfma");
     if (split && !P.defer_combine) {
         hipLaunchKernelGGL((sel_attn_combine_kernel<T, D>), dim3((unsigned)((P.R * P.h + 3) / 4)), dim3(256), 0, st, P);

@@ -21,6 +21,8 @@ struct SelAttnParams {
     int nsplit;
     int map_mode;  // 0 rows linear in blockIdx; 1 workgroup = 4 tokens of one (b,g); 2 = 1 + XCD-aware order
     int defer_combine;  // split-KV: leave the partial records for the caller's own combine pass
+    int fuse_select;    // the kernel first selects the row's ranges from its group scores (select = const SelectParams *, host)
+    const void *select;
 };
 
 struct SelAttnBwdParams {

@@ -114,16 +114,10 @@ int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, i
     return NSA_OK;
 }
 
-int launch_select_topn(const float *p_grp, int64_t R, int S, int G, int t0, const int32_t *t_rows, int S_sel,
-                       int l_sel, int n_top, int force_init, int force_local, int mode, int S_total,
-                       int32_t *out, int W, hipStream_t st) {
-    NSA_CHECK_ARG(R >= 0 && S >= 1 && G >= 1 && S_sel >= 1 && l_sel >= 1 && n_top >= 0, "select: bad sizes");
-    NSA_CHECK_ARG(S_sel <= 64 * 32, "select: S_sel=%d exceeds 2048 selection blocks", S_sel);
-    NSA_CHECK_ARG(force_local >= 0 && force_local <= 30, "select: force_local out of range");
-    SelectParams P{};
-    P.p_grp = p_grp; P.t_rows = t_rows; P.out = out; P.R = R; P.S = S; P.G = G; P.t0 = t0; P.S_sel = S_sel;
-    P.l_sel = l_sel; P.n_top = n_top; P.force_init = force_init ? 1 : 0; P.force_local = force_local; P.mode = mode;
-    P.W = W;
+int select_params_fill(SelectParams *Pp, int S_sel, int l_sel, int n_top, int force_init, int force_local, int mode, int S_total, int W) {
+    SelectParams &P = *Pp;
+    NSA_CHECK_ARG(S_sel >= 1 && S_sel <= 64 * 32 && l_sel >= 1 && n_top >= 0 && force_local >= 0 && force_local <= 30, "select: bad sizes");
+    P.S_sel = S_sel; P.l_sel = l_sel; P.n_top = n_top; P.force_init = force_init ? 1 : 0; P.force_local = force_local; P.mode = mode; P.W = W;
     const int nf_all = P.force_init + force_local;
     if (mode == NSA_SEL_SEQUENTIAL) {
         NSA_CHECK_ARG(W == n_top, "select (sequential): out_width must be n_top");
@@ -144,6 +138,20 @@ int launch_select_topn(const float *p_grp, int64_t R, int S, int G, int t0, cons
     } else {
         NSA_CHECK_ARG(false, "select: unknown mode %d", mode);
     }
+    return NSA_OK;
+}
+
+int launch_select_topn(const float *p_grp, int64_t R, int S, int G, int t0, const int32_t *t_rows, int S_sel,
+                       int l_sel, int n_top, int force_init, int force_local, int mode, int S_total,
+                       int32_t *out, int W, hipStream_t st) {
+    NSA_CHECK_ARG(R >= 0 && S >= 1 && G >= 1 && S_sel >= 1 && l_sel >= 1 && n_top >= 0, "select: bad sizes");
+    NSA_CHECK_ARG(S_sel <= 64 * 32, "select: S_sel=%d exceeds 2048 selection blocks", S_sel);
+    NSA_CHECK_ARG(force_local >= 0 && force_local <= 30, "select: force_local out of range");
+    SelectParams P{};
+    P.p_grp = p_grp; P.t_rows = t_rows; P.out = out; P.R = R; P.S = S; P.G = G; P.t0 = t0; P.S_sel = S_sel;
+    P.l_sel = l_sel; P.n_top = n_top; P.force_init = force_init ? 1 : 0; P.force_local = force_local; P.mode = mode;
+    P.W = W;
+    if (int rc = select_params_fill(&P, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, W)) return rc;
     if (R == 0 || W == 0) return NSA_OK;
     const unsigned grid = (unsigned)((R + 3) / 4);
     const int cand = (S_sel + 63) / 64;

@@ -16,9 +16,10 @@ struct SelectParams {
     int all_valid;     // batched with n_top >= S_sel: select every valid block
 };
 
-// one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS), out = its [W,2] ranges.
+// one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS).  Lane i < min(W, 64) returns
+// range i in (my_s, my_e); ranges beyond the emitted runs are [0, 0).
 template <int CAND>
-__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out) {
+__device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, const float *p, const int t, int &my_s, int &my_e) {
     const int lane = lane_id();
     const int l_sel = P.l_sel, S_sel = P.S_sel;
     const int nvalid_blocks = min(S_sel, (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
@@ -101,7 +102,8 @@ __device__ __forceinline__ void select_topn_row(const SelectParams &P, const flo
     }
 
     // ---- run extraction
-    int my_s = 0, my_e = 0;
+    my_s = 0;
+    my_e = 0;
     int nrun = 0;
     int cur_s = -1, cur_e = -1;  // pending run (block ids), wave uniform
     auto emit = [&]() {
@@ -131,6 +133,14 @@ __device__ __forceinline__ void select_topn_row(const SelectParams &P, const flo
         }
     }
     if (cur_s >= 0) emit();
+}
+
+// same, storing the row's [W,2] ranges
+template <int CAND>
+__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out) {
+    const int lane = lane_id();
+    int my_s, my_e;
+    select_topn_row_regs<CAND>(P, p, t, my_s, my_e);
     if (lane < P.W) {
         out[2 * lane] = my_s;
         out[2 * lane + 1] = my_e;
@@ -144,5 +154,6 @@ __device__ __forceinline__ void select_topn_row(const SelectParams &P, const flo
 
 // host: SelectParams of the sequential selector (decode / per-row prefill), see sel_select.hip
 int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, int force_init, int force_local, int W);
+int select_params_fill(SelectParams *P, int S_sel, int l_sel, int n_top, int force_init, int force_local, int mode, int S_total, int W);
 
 }  // namespace nsa

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from . import _lib
 from .band_attention import batched_causal_attention_compressed, sliding_window_attention
 from .kv_cache import NSA_KV
-from .selection_attention import selection_attention_hip, selection_decode_step
+from .selection_attention import select_and_attend, selection_attention_hip, selection_decode_step
 from .selection_scorer import _DT, _stream, select_topn_ranges_batched, select_topn_ranges_rows, selection_scores, workspace
 
 
@@ -362,12 +362,15 @@ class NSAAttention(nn.Module):
         Qc = Q.contiguous()
         # ---- selected branch (HIP): scores -> ranges -> attention
         p_grp = selection_scores(Qc, kv.K_cmp, meta, scale, causal_skip=True)
-        if self.selector == "batched":
-            ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
+        if native:  # top-n selection inside the attention launch
+            ranges, O_sel = select_and_attend(p_grp, Qc, kv.K_sel, kv.V_sel, meta, self.n_sel, mode=self.selector, scale=scale)
         else:
-            ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+            if self.selector == "batched":
+                ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
+            else:
+                ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+            O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
         self._last_ranges = ranges
-        O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
         # ---- compressed + sliding branches (HIP band kernel)
         O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, scale=scale)
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S], kv._V_win[:, :, :S], self.w, scale=scale)

@@ -141,6 +141,47 @@ def selection_decode_step(Q: torch.Tensor, K_cmp: torch.Tensor, K: torch.Tensor,
     return O, rg
 
 
+def select_and_attend(p_grp: torch.Tensor, Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, meta, n_top: int, *,
+                      mode: str = "batched", t0: int = 0, force_init: bool = True, force_local: int = 2,
+                      scale: Optional[float] = None, return_lse: bool = False):
+    """Prefill (inference): top-n selection from the group scores and the selection attention in ONE native call
+    (nsa_sel_select_attn_fwd; on the MFMA route the selector runs inside the attention kernel).  p_grp [B,S,G,S_sel] fp32.
+    mode "batched" = select_topn_ranges_batched semantics (selection_scorer.py:255-362), "sequential" = select_topn_ranges per
+    row at token t0 + s (:124-249).  Returns (ranges [B,S,G,W,2] int32, O [B,S,G,h,Dv]) -- bit-identical to
+    select_topn_ranges_batched / select_topn_ranges_rows followed by selection_attention_hip."""
+    from .selection_scorer import batched_ranges_width
+
+    dev = _need_gpu(p_grp, Q, K, V)
+    B, S, G, h, Dk = Q.shape
+    S_kv, Dv, S_sel = K.shape[2], V.shape[3], p_grp.shape[-1]
+    if p_grp.shape[:3] != (B, S, G) or p_grp.dtype != torch.float32:
+        raise RuntimeError("select_and_attend: p_grp must be fp32 [B,S,G,S_sel]")
+    if mode == "batched":
+        md, W = _lib.NSA_SEL_BATCHED, batched_ranges_width(S_sel, meta.l_sel, n_top, S, force_init, force_local)
+    elif mode == "sequential":
+        md, W = _lib.NSA_SEL_SEQUENTIAL, n_top
+    else:
+        raise ValueError("mode must be 'batched' or 'sequential'")
+    Qc, Kc, Vc, pg = Q.contiguous(), _prep_kv(K), _prep_kv(V), p_grp.contiguous()
+    ranges = torch.empty((B, S, G, W, 2), dtype=torch.int32, device=dev)
+    O = torch.empty((B, S, G, h, Dv), dtype=V.dtype, device=dev)
+    lse = torch.empty((B, S, G, h), dtype=torch.float32, device=dev) if return_lse else None
+    if O.numel() == 0 or W == 0:
+        O.zero_()
+        return (ranges, O, lse) if return_lse else (ranges, O)
+    L = _lib.lib()
+    dt = _DT[Q.dtype]
+    ws = workspace(dev, L.nsa_sel_attn_fwd_workspace(B, S, G, h, Dk, Dv, W, dt), "attn")
+    rc = L.nsa_sel_select_attn_fwd(pg.data_ptr(), int(t0), None, S_sel, int(meta.l_sel), int(n_top), int(bool(force_init)), int(force_local),
+                                   md, S, ranges.data_ptr(), W, Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), O.data_ptr(),
+                                   lse.data_ptr() if lse is not None else None, B, S, G, h, Dk, Dv, S_kv,
+                                   Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
+                                   dt, float(scale) if scale else 0.0, ws.data_ptr() if ws is not None else None,
+                                   ws.numel() if ws is not None else 0, _stream(dev))
+    _lib.check(rc, "nsa_sel_select_attn_fwd")
+    return (ranges, O, lse) if return_lse else (ranges, O)
+
+
 # the reference's executor names, bound to the HIP implementation
 grouped_selection_attention_masked = selection_attention_hip
 selection_attention_cuda = selection_attention_hip

@@ -304,3 +304,27 @@ def test_properties_full_size_64k(nv):
     # duplicated ranges change nothing
     O_dup = nv.selection_attention_hip(Q, K, V, torch.cat([rg, rg], dim=3)).float()
     assert (O - O_dup).abs().max().item() <= 1e-2
+
+
+@pytest.mark.parametrize("mode", ["batched", "sequential"])
+@pytest.mark.parametrize("B,S,G,dtype", [(2, 4096, 2, torch.bfloat16), (1, 16384, 2, torch.bfloat16), (1, 700, 3, torch.float16),
+                                         (1, 300, 2, torch.float32), (1, 40, 1, torch.bfloat16)])
+def test_select_and_attend_equals_separate_calls(nv, mode, B, S, G, dtype):
+    """top-n selection inside the attention launch (MFMA route, enough rows) and its two-launch fallbacks: ranges bit-exact and
+    O identical to select_topn_ranges_{batched,rows} followed by selection_attention_hip"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S + G)
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).to(dtype)  # noqa: E731
+    Q, K, V = mk(B, S, G, 6, 64), mk(B, G, S, 64), mk(B, G, S, 64)
+    p_grp = torch.rand(B, S, G, meta.S_sel, device="cuda", generator=g)
+    p_grp[:, :, :, ::7] = 0.25  # ties
+    if mode == "batched":
+        r_ref = nv.select_topn_ranges_batched(p_grp, meta, 16, S)
+    else:
+        r_ref = nv.select_topn_ranges_rows(p_grp, meta, 16, 0)
+    O_ref, lse_ref = nv.selection_attention_hip(Q, K, V, r_ref, return_lse=True)
+    r, O, lse = nv.select_and_attend(p_grp, Q, K, V, meta, 16, mode=mode, return_lse=True)
+    torch.cuda.synchronize()
+    assert r.shape == r_ref.shape and torch.equal(r, r_ref)
+    assert torch.equal(O, O_ref) and torch.equal(lse, lse_ref)
