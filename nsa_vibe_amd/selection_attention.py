@@ -152,6 +152,8 @@ def select_and_attend(p_grp: torch.Tensor, Q: torch.Tensor, K: torch.Tensor, V: 
     from .selection_scorer import batched_ranges_width
 
     dev = _need_gpu(p_grp, Q, K, V)
+    if torch.is_grad_enabled() and (Q.requires_grad or K.requires_grad or V.requires_grad):
+        raise RuntimeError("select_and_attend is the inference form; with autograd use select_topn_ranges_* + selection_attention_hip")
     B, S, G, h, Dk = Q.shape
     S_kv, Dv, S_sel = K.shape[2], V.shape[3], p_grp.shape[-1]
     if p_grp.shape[:3] != (B, S, G) or p_grp.dtype != torch.float32:
