@@ -177,6 +177,15 @@ NSA_API int nsa_cmp_pool_bwd(const nsa_layer_desc *L, int B, int S, int n_cmp, c
                      void *dV_raw, void *stream);
 NSA_API int nsa_gate_combine_bwd(const nsa_layer_desc *L, const void *dO, const void *O_cmp, const void *O_sel, const void *O_win,
                          const float *gates, void *dO_cmp, void *dO_sel, void *dO_win, float *dgates, int64_t R, void *stream);
+/* Prefill of the whole layer between the two big GEMMs, in one call (nsa_attention.py:978-1448 / 1521-1723): proj [B,S,NQ+3GDk+3GDv]
+ * (= x @ W_qkv^T) -> RoPE + append of the S tokens into the EMPTY caches -> compressed-token pooling -> selection scores ->
+ * top-n + selection attention -> sliding and compressed branches -> gates + combine -> O_mix [B,S,G*h*Dv] (input of the output
+ * projection).  selector = NSA_SEL_BATCHED or NSA_SEL_SEQUENTIAL; ranges_out [B,S,G,W,2] with W = nsa_batched_ranges_width(S, ...)
+ * resp. n_sel; gates_out [B,S,G,3] fp32 nullable.  csc_* / S_sel: Eq.9 map of the metadata for S tokens. */
+NSA_API size_t nsa_layer_prefill_workspace(const nsa_layer_desc *L, int B, int S, int S_sel);
+NSA_API int nsa_layer_prefill(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, int S, int selector,
+                      const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out,
+                      int out_width, void *O_mix, float *gates_out, void *workspace, size_t workspace_bytes, void *stream);
 /* One decode step of the whole layer in one call (nsa_attention.py:509-830, decode branch): x [B,dim] is the new token at
  * position t (= tokens already cached); appends it to the caches, emits a compressed token when due, runs the three branches,
  * the gate and the output projection -> y [B,dim].  csc_* / S_sel: the Eq.9 map of the block metadata covering t

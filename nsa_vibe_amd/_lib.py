@@ -53,6 +53,8 @@ SIGNATURES = {
     "nsa_rope_cache_append_bwd": (_i, [_pl, _i, _i, _i] + [_vp] * 8 + [_vp]),
     "nsa_cmp_pool_bwd": (_i, [_pl, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "nsa_gate_combine_bwd": (_i, [_pl] + [_vp] * 9 + [_i64, _vp]),
+    "nsa_layer_prefill_workspace": (_sz, [_pl, _i, _i, _i]),
+    "nsa_layer_prefill": (_i, [_pl, _pk, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nsa_layer_decode_step_workspace": (_sz, [_pl, _i, _i]),
     "nsa_layer_decode_step": (_i, [_pl, _pk, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nsa_band_attn_bwd_workspace": (_sz, [_i] * 9),

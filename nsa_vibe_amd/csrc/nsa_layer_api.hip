@@ -125,6 +125,82 @@ int nsa_gate_combine_bwd(const nsa_layer_desc *L, const void *dO, const void *O_
     return launch_gate_combine_bwd(P, dO, gates, dO_cmp, dO_sel, dO_win, dgates, L->dtype, (hipStream_t)stream);
 }
 
+// prefill workspace: Q | p_grp | O_cmp | O_sel | O_win | scorer scratch | attention scratch | band scratch
+struct PrefillWs {
+    size_t q, pgrp, ocmp, osel, owin, sc, att, band, total, sc_bytes, att_bytes, band_bytes;
+};
+static PrefillWs prefill_ws(const nsa_layer_desc *L, int B, int S, int S_sel) {
+    PrefillWs w;
+    const size_t e = esize(L->dtype);
+    const size_t NQ = (size_t)L->G * L->h * L->Dk, NO = (size_t)L->G * L->h * L->Dv;
+    const int n_cmp = S < L->l ? 0 : (S - L->l) / L->d + 1;
+    size_t o = 0;
+    w.q = o; o += up256((size_t)B * S * NQ * e);
+    w.pgrp = o; o += up256(sizeof(float) * (size_t)B * S * L->G * (size_t)(S_sel > 0 ? S_sel : 1));
+    w.ocmp = o; o += up256((size_t)B * S * NO * e);
+    w.osel = o; o += up256((size_t)B * S * NO * e);
+    w.owin = o; o += up256((size_t)B * S * NO * e);
+    w.sc_bytes = nsa_sel_scores_workspace(B, S, L->G, L->h, L->Dk, n_cmp, S_sel, L->l, L->d, L->l_sel, L->dtype, 0);
+    const size_t sc1 = nsa_sel_scores_workspace(B, S, L->G, L->h, L->Dk, n_cmp, S_sel, L->l, L->d, L->l_sel, L->dtype, 1);
+    if (sc1 > w.sc_bytes) w.sc_bytes = sc1;  // the generic route may be taken for unaligned inputs
+    w.sc = o; o += up256(w.sc_bytes);
+    w.att_bytes = nsa_sel_attn_fwd_workspace(B, S, L->G, L->h, L->Dk, L->Dv, L->n_sel, L->dtype);
+    w.att = o; o += up256(w.att_bytes);
+    w.band_bytes = nsa_band_attn_fwd_workspace(B, S, L->G, L->h, L->Dk, L->Dv, L->dtype);
+    w.band = o; o += up256(w.band_bytes);
+    w.total = o;
+    return w;
+}
+
+size_t nsa_layer_prefill_workspace(const nsa_layer_desc *L, int B, int S, int S_sel) {
+    if (!L || !dt_ok(L->dtype) || B < 1 || S < 1) return 0;
+    return prefill_ws(L, B, S, S_sel).total;
+}
+
+int nsa_layer_prefill(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, int S, int selector, const int32_t *csc_ptr,
+                      const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, int out_width, void *O_mix,
+                      float *gates_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_layer(L, "layer_prefill")) return rc;
+    if (int rc = check_kv(kv, "layer_prefill")) return rc;
+    NSA_CHECK_ARG(proj && O_mix && ranges_out, "layer_prefill: null pointer");
+    NSA_CHECK_ARG(S >= 1 && S <= kv->S_max, "layer_prefill: %d tokens exceed the cache capacity %d", S, kv->S_max);
+    NSA_CHECK_ARG(S_sel >= 1 && (int64_t)S_sel * L->l_sel >= S, "layer_prefill: block metadata (S_sel=%d) does not cover %d tokens", S_sel, S);
+    NSA_CHECK_ARG(selector == NSA_SEL_BATCHED || selector == NSA_SEL_SEQUENTIAL, "layer_prefill: unknown selector %d", selector);
+    const int B = kv->B, G = L->G, h = L->h, Dk = L->Dk, Dv = L->Dv, dt = L->dtype;
+    const PrefillWs W = prefill_ws(L, B, S, S_sel);
+    NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 256 == 0) && workspace_bytes >= W.total,
+                  "layer_prefill: workspace missing, misaligned or too small");
+    unsigned char *ws = (unsigned char *)workspace;
+    void *Q = ws + W.q, *Ocmp = ws + W.ocmp, *Osel = ws + W.osel, *Owin = ws + W.owin;
+    float *p_grp = (float *)(ws + W.pgrp);
+    const int n_cmp = S < L->l ? 0 : (S - L->l) / L->d + 1;
+    NSA_CHECK_ARG(n_cmp <= kv->n_cmp_max, "layer_prefill: compressed cache too small");
+    if (int rc = nsa_rope_cache_append(L, kv, proj, Q, S, 0, stream)) return rc;
+    if (int rc = nsa_cmp_pool_append(L, kv, 0, n_cmp, stream)) return rc;
+    const int64_t ksb = (int64_t)G * kv->S_max * Dk, ksg = (int64_t)kv->S_max * Dk;
+    const int64_t vsb = (int64_t)G * kv->S_max * Dv, vsg = (int64_t)kv->S_max * Dv;
+    const int64_t kcb = (int64_t)G * kv->n_cmp_max * Dk, kcg = (int64_t)kv->n_cmp_max * Dk;
+    const int64_t vcb = (int64_t)G * kv->n_cmp_max * Dv, vcg = (int64_t)kv->n_cmp_max * Dv;
+    const float scale = 1.0f / sqrtf((float)Dk);
+    // selected branch: scores (blocks no selector can read at row t are skipped) -> top-n + attention
+    const bool aligned = ((uintptr_t)kv->K_cmp % 16 == 0) && kcb % 8 == 0 && kcg % 8 == 0 && Dk % 8 == 0;
+    if (int rc = nsa_sel_scores(Q, kv->K_cmp, p_grp, B, S, G, h, Dk, n_cmp, kcb, kcg, Dk, csc_ptr, csc_rows, csc_vals, S_sel, L->l, L->d,
+                                L->l_sel, 1, aligned ? 0 : 1, dt, scale, ws + W.sc, W.sc_bytes, stream))
+        return rc;
+    if (int rc = nsa_sel_select_attn_fwd(p_grp, 0, nullptr, S_sel, L->l_sel, L->n_sel, 1, 2, selector, S, ranges_out, out_width, Q, kv->K_sel,
+                                         kv->V_sel, Osel, nullptr, B, S, G, h, Dk, Dv, S, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale, ws + W.att,
+                                         W.att_bytes, stream))
+        return rc;
+    // sliding and compressed branches
+    if (int rc = nsa_band_attn_fwd(Q, kv->K_win, kv->V_win, Owin, nullptr, B, S, G, h, Dk, Dv, S, ksb, ksg, Dk, vsb, vsg, Dv, 0, 0, 1, 0, L->w,
+                                   dt, scale, 0, ws + W.band, W.band_bytes, stream))
+        return rc;
+    if (int rc = nsa_band_attn_fwd(Q, kv->K_cmp, kv->V_cmp, Ocmp, nullptr, B, S, G, h, Dk, Dv, n_cmp, kcb, kcg, Dk, vcb, vcg, Dv, 0, L->l, L->d,
+                                   1, 1 << 30, dt, scale, 0, ws + W.band, W.band_bytes, stream))
+        return rc;
+    return nsa_gate_combine(L, Q, Ocmp, Osel, Owin, O_mix, gates_out, (int64_t)B * S * G, stream);
+}
+
 // workspace: proj | Q | O_cmp | O_sel | O_win | O_mix | ranges | selection-decode scratch | band scratch
 struct DecodeWs {
     size_t proj, q, ocmp, osel, owin, omix, ranges, sel, band, band2, total, sel_bytes, band_bytes;

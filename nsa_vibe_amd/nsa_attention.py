@@ -335,20 +335,7 @@ class NSAAttention(nn.Module):
         assert kv.t == 0, "prefill expects an empty cache"
         native = self._native_ok(x)
         if native:
-            # one fused projection GEMM, then RoPE + cache append and the compressed-token pooling as native kernels
-            if S > kv._K_sel.shape[2]:
-                raise RuntimeError(f"NSA_KV capacity exceeded: {S} > S_max={kv.S_max}")
-            L, dev = _lib.lib(), x.device
-            desc, W_qkv = self._layer_desc()
-            kd = self._kv_desc(kv)
-            proj = F.linear(x, W_qkv)
-            Q = torch.empty((B, S, self.n_kv_groups, self.h_per_group, self.d_k), dtype=x.dtype, device=dev)
-            _lib.check(L.nsa_rope_cache_append(ctypes.byref(desc), ctypes.byref(kd), proj.data_ptr(), Q.data_ptr(), S, 0, _stream(dev)),
-                       "nsa_rope_cache_append")
-            kv.t = S
-            n_cmp = 0 if S < self.l else (S - self.l) // self.d + 1
-            _lib.check(L.nsa_cmp_pool_append(ctypes.byref(desc), ctypes.byref(kd), 0, n_cmp, _stream(dev)), "nsa_cmp_pool_append")
-            kv.n_cmp = n_cmp
+            return self._prefill_native(x, kv)
         elif self._train_native_ok(x):
             return self._prefill_train_native(x, kv)
         else:
@@ -362,26 +349,50 @@ class NSAAttention(nn.Module):
         Qc = Q.contiguous()
         # ---- selected branch (HIP): scores -> ranges -> attention
         p_grp = selection_scores(Qc, kv.K_cmp, meta, scale, causal_skip=True)
-        if native:  # top-n selection inside the attention launch
-            ranges, O_sel = select_and_attend(p_grp, Qc, kv.K_sel, kv.V_sel, meta, self.n_sel, mode=self.selector, scale=scale)
+        if self.selector == "batched":
+            ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
         else:
-            if self.selector == "batched":
-                ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
-            else:
-                ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
-            O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
+            ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+        O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
         self._last_ranges = ranges
         # ---- compressed + sliding branches (HIP band kernel)
         O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, scale=scale)
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S], kv._V_win[:, :, :S], self.w, scale=scale)
-        if native:
-            O = torch.empty_like(O_sel)
-            gates = torch.empty((B, S, self.n_kv_groups, 3), dtype=torch.float32, device=x.device)
-            _lib.check(L.nsa_gate_combine(ctypes.byref(desc), Qc.data_ptr(), O_cmp.data_ptr(), O_sel.data_ptr(), O_win.data_ptr(),
-                                          O.data_ptr(), gates.data_ptr(), B * S * self.n_kv_groups, _stream(dev)), "nsa_gate_combine")
-            self._last_gates = gates
-            return self.out(O.reshape(B, S, self.n_heads * self.d_v)), kv
         return self._combine(Q, O_cmp, O_sel, O_win), kv
+
+    def _prefill_native(self, x: torch.Tensor, kv: NSA_KV):
+        """inference prefill: fused projection GEMM -> ONE native call for everything up to the output projection
+        (nsa_layer_prefill: RoPE + cache append, pooling, scores, top-n + selection attention, sliding / compressed branches,
+        gates + combine) -> output GEMM"""
+        from .selection_scorer import batched_ranges_width
+
+        B, S, _ = x.shape
+        if S > kv._K_sel.shape[2]:
+            raise RuntimeError(f"NSA_KV capacity exceeded: {S} > S_max={kv.S_max}")
+        L, dev = _lib.lib(), x.device
+        desc, W_qkv = self._layer_desc()
+        kd = self._kv_desc(kv)
+        meta = kv.ensure_meta(S)
+        proj = F.linear(x, W_qkv)
+        G = self.n_kv_groups
+        if self.selector == "batched":
+            mode, W = _lib.NSA_SEL_BATCHED, batched_ranges_width(meta.S_sel, self.l_sel, self.n_sel, S, True, 2)
+        else:
+            mode, W = _lib.NSA_SEL_SEQUENTIAL, self.n_sel
+        ranges = torch.empty((B, S, G, W, 2), dtype=torch.int32, device=dev)
+        gates = torch.empty((B, S, G, 3), dtype=torch.float32, device=dev)
+        O = torch.empty((B, S, self.n_heads * self.d_v), dtype=x.dtype, device=dev)
+        ws = workspace(dev, L.nsa_layer_prefill_workspace(ctypes.byref(desc), B, S, int(meta.S_sel)) + 256, "layer_prefill")
+        wptr = (ws.data_ptr() + 255) & ~255
+        cptr, crows, cvals = meta.device_csc(dev)
+        rc = L.nsa_layer_prefill(ctypes.byref(desc), ctypes.byref(kd), proj.data_ptr(), S, mode, cptr.data_ptr(), crows.data_ptr(),
+                                 cvals.data_ptr(), int(meta.S_sel), ranges.data_ptr(), W, O.data_ptr(), gates.data_ptr(), wptr,
+                                 ws.numel() - (wptr - ws.data_ptr()), _stream(dev))
+        _lib.check(rc, "nsa_layer_prefill")
+        kv.t = S
+        kv.n_cmp = 0 if S < self.l else (S - self.l) // self.d + 1
+        self._last_ranges, self._last_gates = ranges, gates
+        return self.out(O), kv
 
     def _prefill_train_native(self, x: torch.Tensor, kv: NSA_KV):
         """training forward: one fused projection GEMM, then every stage is a differentiable native op (the attention branches
