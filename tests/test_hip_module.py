@@ -320,3 +320,29 @@ def test_native_vs_eager_over_odd_configurations(cfg, selector, dtype, monkeypat
             assert err.max().item() <= 5e-4
         else:  # bf16: selection may flip on near ties between the two arithmetic orders; bound the typical row
             assert err.median().item() <= 6e-2 and (err <= 6e-2).float().mean().item() >= 0.85
+
+
+@pytest.mark.parametrize("branch", ["win", "sel"])
+def test_small_sequence_equals_full_causal_attention(branch):
+    """analog of the reference's test_equiv_small.py (:52-101): with the gate forced to one branch and that branch covering every
+    past token (w >= S, resp. n_sel * l' >= S) the layer is plain causal attention over that branch's K/V.  (The reference's
+    version passes through its first-key quirk; here both sides are true softmax attention.)"""
+    import math
+
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    torch.manual_seed(0)
+    B, S, dim, H, G, D = 2, 40, 64, 4, 2, 16
+    m = NSAAttention(dim, H, G, D, D, l=4, d=2, l_sel=4, n_sel=16, w=64).cuda().float().eval()
+    with torch.no_grad():
+        m.gate.fc2.bias.copy_(torch.tensor([-1000.0, -1000.0, 1000.0] if branch == "win" else [-1000.0, 1000.0, -1000.0]))
+        x = torch.randn(B, S, dim, device="cuda")
+        y, _ = m(x, m.new_kv(B, S, "cuda", torch.float32), prefill=True)
+        pos = torch.arange(S, device="cuda")
+        Q, K_sel, V_sel, K_win, V_win, _, _ = m._project(x, pos)
+        K, V = (K_win, V_win) if branch == "win" else (K_sel, V_sel)
+        s = torch.einsum("bsghd,bgkd->bsghk", Q, K) / math.sqrt(D)
+        causal = torch.arange(S, device="cuda").view(1, -1) <= pos.view(-1, 1)
+        p = torch.softmax(s.masked_fill(~causal.view(1, S, 1, 1, S), float("-inf")), dim=-1)
+        ref = m.out(torch.einsum("bsghk,bgkd->bsghd", p, V).reshape(B, S, H * D))
+    assert (y - ref).abs().mean().item() < 1e-5 and (y - ref).abs().max().item() < 1e-4
