@@ -250,6 +250,67 @@ def _cpu_model():
     return "unknown"
 
 
+def train_mode(nv, args, dist, world, rank, device):
+    """DDP training step of one NSAAttention layer (m7c shape, bf16): every rank B sequences, bucketed gradient all-reduce over
+    RCCL overlapped with the backward by DistributedDataParallel; time = max over ranks, value = whole-job tokens/s."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    B, S = args.batch, args.seq
+    torch.manual_seed(0)  # identical initial weights on every rank
+    layer = nv.NSAAttention(768, 12, G, D, D, L_CMP, D_CMP, L_SEL, N_SEL, 512, selector="batched").to(device).to(torch.bfloat16).train()
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            return self.m(x, self.m.new_kv(x.shape[0], x.shape[1], x.device, x.dtype), prefill=True)[0]
+
+    model = Wrap(layer)
+    if dist is not None:
+        model = DDP(model, device_ids=[device.index], bucket_cap_mb=25)
+    opt = torch.optim.SGD(layer.parameters(), lr=1e-4)
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + rank)
+    x = torch.randn(B, S, 768, device=device, generator=g).bfloat16()
+    go = torch.randn(B, S, 768, device=device, generator=g).bfloat16()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        model(x).backward(go)
+        opt.step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "nsa_layer_train_tok_per_s", "value": world * B * S / (elapsed / args.steps), "unit": "tok/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"one m7c_125m NSAAttention layer, forward+backward+SGD step, S={S}, B={B} per GPU, DDP "
+                                   f"(gradient all-reduce of {sum(p.numel() for p in layer.parameters())} bf16 parameters per step)",
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world} (DistributedDataParallel over RCCL)"}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +319,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--no-extra", action="store_true", help="skip the decode / 16k / 64k extras and the CPU baseline")
+    ap.add_argument("--train", action="store_true",
+                    help="instead of the hot path: forward+backward of the whole NSAAttention layer under DistributedDataParallel "
+                         "(BASELINE config 5: gradient all-reduce over RCCL/xGMI, batch sharded over the ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,6 +342,8 @@ def main():
     import nsa_vibe_amd as nv  # fails loudly if libnsa_sel_hip.so is missing
 
     B, S = args.batch, args.seq
+    if args.train:
+        return train_mode(nv, args, dist, world, rank, device)
     meta, Q, Kc, K, V = make_inputs(nv, B, S, device, 1234 + rank)
 
     def barrier():

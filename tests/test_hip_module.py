@@ -346,3 +346,51 @@ def test_small_sequence_equals_full_causal_attention(branch):
         p = torch.softmax(s.masked_fill(~causal.view(1, S, 1, 1, S), float("-inf")), dim=-1)
         ref = m.out(torch.einsum("bsghk,bgkd->bsghd", p, V).reshape(B, S, H * D))
     assert (y - ref).abs().mean().item() < 1e-5 and (y - ref).abs().max().item() < 1e-4
+
+
+def test_layer_trains_under_ddp_single_rank():
+    """config 5 plumbing: the layer (custom autograd ops, cache-view outputs) wrapped in DistributedDataParallel over RCCL
+    (backend "nccl", world size 1 on this box): forward/backward run and the gradients equal the unwrapped layer's"""
+    import os
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(9)
+        m = NSAAttention(256, 8, 2, 64, 64, l=32, d=16, l_sel=64, n_sel=4, w=96, selector="batched").cuda().bfloat16().train()
+        B, S = 2, 200
+        x = torch.randn(B, S, 256, device="cuda", dtype=torch.bfloat16)
+        go = torch.randn(B, S, 256, device="cuda", dtype=torch.bfloat16)
+
+        class Wrap(torch.nn.Module):  # DDP wants a forward(x) -> tensor
+            def __init__(self, layer):
+                super().__init__()
+                self.layer = layer
+
+            def forward(self, x):
+                return self.layer(x, self.layer.new_kv(x.shape[0], x.shape[1], x.device, x.dtype), prefill=True)[0]
+
+        out0 = Wrap(m)(x)
+        out0.backward(go)
+        ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+        m.zero_grad(set_to_none=True)
+        ddp = DDP(Wrap(m), device_ids=[0])
+        out1 = ddp(x)
+        out1.backward(go)
+        torch.cuda.synchronize()
+        assert torch.equal(out0, out1)
+        for n, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            assert (p.grad.float() - ref[n].float()).abs().max().item() <= 1e-2 * max(1.0, ref[n].float().abs().max().item()), n
+    finally:
+        if created:
+            dist.destroy_process_group()
