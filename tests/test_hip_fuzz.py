@@ -1,0 +1,145 @@
+"""Seeded randomized sweeps of the three kernel families against the oracle: shapes, dtypes, strides, degenerate ranges, ties.
+Every case is small enough for the CPU oracle; the point is coverage of the dispatch (MFMA / generic, split-KV, XCD-aware and
+plain mappings, head counts that do not divide 16, D in {32, 64, 128}) rather than size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 1e-2}
+
+
+@pytest.fixture(scope="module")
+def nv():
+    import nsa_vibe_amd
+
+    assert torch.cuda.is_available()
+    return nsa_vibe_amd
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rounded(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).float().numpy()
+
+
+def _bound(ref, dtype):
+    return TOL[dtype] * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_selection_attention(nv, orc, seed):
+    rng = np.random.default_rng(7000 + seed)
+    dtype = [torch.bfloat16, torch.float16, torch.float32][seed % 3]
+    B, G = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    h = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 16]))
+    D = int(rng.choice([32, 64, 64, 64, 128]))
+    S, S_kv, n = int(rng.integers(1, 90)), int(rng.integers(1, 700)), int(rng.integers(1, 20))
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    S_alloc = S_kv + int(rng.integers(0, 40))  # K/V are views of a larger cache
+    K = rng.standard_normal((B, G, S_alloc, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_alloc, D), dtype=np.float32)
+    st = rng.integers(-20, S_kv + 20, size=(B, S, G, n))
+    ln = rng.integers(-30, 130, size=(B, S, G, n))
+    rg = np.stack([st, st + ln], axis=-1).astype(np.int32)
+    rg[rng.random((B, S, G)) < 0.1] = 0  # empty rows
+    Kd, Vd = dev(K, dtype)[:, :, :S_kv], dev(V, dtype)[:, :, :S_kv]
+    O, lse = nv.selection_attention_hip(dev(Q, dtype), Kd, Vd, dev(rg), return_lse=True)
+    ref, ref_lse = orc.sel_attention_masked(rounded(Q, dtype), rounded(K[:, :, :S_kv], dtype), rounded(V[:, :, :S_kv], dtype), rg, return_lse=True)
+    got = O.float().cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - ref).max() <= _bound(ref, dtype)
+    assert np.array_equal(np.isfinite(lse.cpu().numpy()), np.isfinite(ref_lse))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_band_attention(nv, orc, seed):
+    from nsa_vibe_amd.band_attention import band_attention_hip
+
+    rng = np.random.default_rng(8000 + seed)
+    dtype = [torch.bfloat16, torch.float16, torch.float32][seed % 3]
+    B, G = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    h = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 16]))
+    D = int(rng.choice([32, 64, 64, 64, 128]))
+    S = int(rng.integers(1, 400))
+    if seed % 2 == 0:  # sliding window, possibly a decode-style offset
+        band = dict(t0=int(rng.integers(0, 50)) if seed % 4 == 0 else 0, a=0, dd=1, c=0, w=int(rng.integers(0, 200)))
+        S_kv = band["t0"] + S + int(rng.integers(0, 10)) - int(rng.integers(0, 5))
+    else:  # compressed schedule
+        l = int(rng.choice([8, 16, 32]))
+        d = int(rng.choice([d_ for d_ in (4, 8, 16, 32) if l % d_ == 0]))
+        band = dict(t0=0, a=l, dd=d, c=1, w=2 ** 30)
+        S_kv = max(0, (S - l) // d + 1 + int(rng.integers(-2, 3)))
+    S_kv = max(S_kv, 0)
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, max(S_kv, 1), D), dtype=np.float32)[:, :, :S_kv]
+    V = rng.standard_normal((B, G, max(S_kv, 1), D), dtype=np.float32)[:, :, :S_kv]
+    O, lse = band_attention_hip(dev(Q, dtype), dev(K, dtype), dev(V, dtype), return_lse=True, **band)
+    ref, ref_lse = orc.band_attention(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), return_lse=True, **band)
+    got = O.float().cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - ref).max() <= _bound(ref, dtype)
+    assert np.array_equal(np.isfinite(lse.cpu().numpy()), np.isfinite(ref_lse))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_selectors(nv, orc, seed):
+    rng = np.random.default_rng(9000 + seed)
+    l_sel = int(rng.choice([16, 32, 64]))
+    d = int(rng.choice([d_ for d_ in (8, 16) if l_sel % d_ == 0]))
+    l = int(rng.choice([d, 2 * d]))
+    S = int(rng.integers(1, 1500))
+    n_top = int(rng.integers(1, 24))
+    B, G = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+    m = nv.build_block_meta(S, l, d, l_sel, n_top, 64)
+    om = orc.build_block_meta(S, l, d, l_sel, n_top, 64)
+    p = rng.random((B, S, G, m.S_sel), dtype=np.float32)
+    p[rng.random(p.shape) < 0.3] = 0.5  # many exact ties
+    if seed % 5 == 0:
+        p[:] = 0.0
+    r = nv.select_topn_ranges_batched(dev(p), m, n_top, S)
+    assert np.array_equal(r.cpu().numpy(), orc.select_topn_ranges_batched(p, om, n_top, S))
+    t = int(rng.integers(0, S))
+    r1 = nv.select_topn_ranges(dev(p[:, t]), m, n_top, t)
+    ref1 = orc.select_topn_ranges(p[:, t], om, n_top, t)
+    a, b = orc.normalise_ranges(r1.cpu().numpy()), orc.normalise_ranges(ref1)
+    assert a == b
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_backward(nv, orc, seed):
+    """selection-attention and band backward (MFMA kernels for bf16/f16 D = 64, generic otherwise) vs the oracle's fp64 backward"""
+    from nsa_vibe_amd.band_attention import band_attention_hip
+
+    rng = np.random.default_rng(9500 + seed)
+    dtype = [torch.bfloat16, torch.float16, torch.float32][seed % 3]
+    B, G = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+    h = int(rng.choice([1, 3, 6, 8, 16]))
+    D = 64 if seed % 4 else 32
+    S, n = int(rng.integers(2, 150)), int(rng.integers(1, 8))
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S, D), dtype=np.float32)
+    dO = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    st = rng.integers(0, S, size=(B, S, G, n))
+    rg = np.stack([st, np.minimum(st + rng.integers(0, 70, size=st.shape), S)], axis=-1).astype(np.int32)
+    tol = 2e-2 if dtype != torch.float32 else 2e-3
+
+    def check(grads, refs):
+        for got, ref, name in zip(grads, refs, ("dQ", "dK", "dV")):
+            g = got.float().cpu().numpy()
+            assert np.isfinite(g).all(), name
+            assert np.abs(g - ref).max() <= tol * max(1.0, np.abs(ref).max()), name
+
+    q, k, v = (dev(x, dtype).requires_grad_(True) for x in (Q, K, V))
+    nv.selection_attention_hip(q, k, v, dev(rg)).backward(dev(dO, dtype))
+    check((q.grad, k.grad, v.grad), orc.sel_attention_masked_bwd(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), rg, rounded(dO, dtype)))
+    band = dict(w=int(rng.integers(1, 100))) if seed % 2 else dict(a=16, dd=8, c=1)
+    S_kv = S if "w" in band else max((S - 16) // 8 + 1, 0)
+    q, k, v = (dev(x, dtype).requires_grad_(True) for x in (Q, K[:, :, :S_kv], V[:, :, :S_kv]))
+    band_attention_hip(q, k, v, **band).backward(dev(dO, dtype))
+    if S_kv > 0:
+        check((q.grad, k.grad, v.grad), orc.band_attention_bwd(rounded(Q, dtype), rounded(K[:, :, :S_kv], dtype), rounded(V[:, :, :S_kv], dtype),
+                                                                rounded(dO, dtype), **band))
