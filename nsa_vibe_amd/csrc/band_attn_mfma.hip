@@ -17,7 +17,9 @@
 
 namespace nsa {
 
-template <typename T, int NT, bool SPLIT>
+// STAGE 1: tiles come by LDS-DMA; STAGE 0: register staging (global loads issued behind the fragment reads, ds_write at the top of the
+// next iteration): the compute-bound NT = 3 form spends ~19 % of a tile issuing its 8 DMA instructions, plain loads issue faster.
+template <typename T, int NT, bool SPLIT, int STAGE>
 __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const unsigned bid) {
     using M = MfmaT<T>;
     using G_ = Geo<64>;
@@ -140,6 +142,26 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
 #endif
     };
 
+    typedef __attribute__((ext_vector_type(4))) unsigned int bu32x4;
+    u32x4 kreg[G_::NLD], vreg[G_::NLD];
+    uint32_t kwr[G_::NLD], vwr[G_::NLD];
+#pragma unroll
+    for (int i = 0; i < G_::NLD; ++i) {
+        const int r = i * G_::RPI + ld_row;
+        kwr[i] = r * G_::ROWB + ((ld_piece ^ G_::swz_k(r)) << 4);
+        vwr[i] = r * G_::ROWB + ((((ld_piece >> 1) ^ G_::swz_v(r)) << 5) | ((ld_piece & 1) << 4));
+    }
+    auto issue_loads = [&](int tok0) {
+        const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);
+        const int last = P.S_kv - 1 - tok0;
+#pragma unroll
+        for (int i = 0; i < G_::NLD; ++i) {
+            const int rc = min(i * G_::RPI + ld_row, last);
+            kreg[i] = __builtin_bit_cast(u32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(krs, rc * krowb32 + ld_piece * 16, ks, 0));
+            vreg[i] = __builtin_bit_cast(u32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(vrs, rc * vrowb32 + ld_piece * 16, vs, 0));
+        }
+    };
+
     f32x4 o[NT][4];
     float mrun[NT], lrun[NT];
 #pragma unroll
@@ -159,13 +181,25 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         tile = (int)(((int64_t)ntile_all * sp) / P.nsplit);
         tile_end = (int)(((int64_t)ntile_all * (sp + 1)) / P.nsplit);
     }
-    if (tile < tile_end) issue_dma(klo + 32 * tile);
+    if (tile < tile_end) {
+        if (STAGE == 1) issue_dma(klo + 32 * tile);
+        else issue_loads(klo + 32 * tile);
+    }
 
     for (; tile < tile_end; ++tile) {
         const int tok0 = klo + 32 * tile;
         x8 kfr[2][2];
         x8 va[4];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is a vmcnt event
+        if (STAGE == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is a vmcnt event
+        } else {
+#pragma unroll
+            for (int i = 0; i < G_::NLD; ++i) {
+                *(u32x4 *)(kl + kwr[i]) = kreg[i];
+                *(u32x4 *)(vl + vwr[i]) = vreg[i];
+            }
+            wave_lds_fence();
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -179,9 +213,14 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
                 va[m][4 + j] = hi[j];
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffers may be refilled
-        __builtin_amdgcn_sched_barrier(0);
-        if (tile + 1 < tile_end) issue_dma(tok0 + 32);
+        if (STAGE == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffers may be refilled
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + 1 < tile_end) issue_dma(tok0 + 32);
+        } else {
+            if (tile + 1 < tile_end) issue_loads(tok0 + 32);
+            wave_lds_fence();  // the fragment reads above are ordered before next iteration's ds_writes
+        }
 
         const bool interior = tok0 >= lo_max && tok0 + 32 <= hi_min;  // every key valid for every slot
         // S^T of all column tiles first, ONE slow-path decision per key tile: the common path below is straight-line code, so
@@ -282,16 +321,16 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
     }
 }
 
-template <typename T, int NT, bool SPLIT>
+template <typename T, int NT, bool SPLIT, int STAGE>
 __global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
-    band_attn_body<T, NT, SPLIT>(P, blockIdx.x);
+    band_attn_body<T, NT, SPLIT, STAGE>(P, blockIdx.x);
 }
 
 // decode: the sliding and the compressed branch of one step in ONE launch (two argument blocks, split-KV form)
 template <typename T>
 __global__ __launch_bounds__(256) void band_attn_fwd_dual_kernel(BandAttnParams P0, BandAttnParams P1, unsigned grid0) {
-    if (blockIdx.x < grid0) band_attn_body<T, 1, true>(P0, blockIdx.x);
-    else band_attn_body<T, 1, true>(P1, blockIdx.x - grid0);
+    if (blockIdx.x < grid0) band_attn_body<T, 1, true, 1>(P0, blockIdx.x);
+    else band_attn_body<T, 1, true, 1>(P1, blockIdx.x - grid0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -381,7 +420,7 @@ __global__ __launch_bounds__(256) void band_attn_bwd_dq_kernel(BandAttnParams P,
     [[maybe_unused]] const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + G_::ROWB);
     [[maybe_unused]] const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + G_::ROWB);
     [[maybe_unused]] const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
-    const int ld_row = lane / G_::PIECES, ld_piece = lane % G_::PIECES;
+    [[maybe_unused]] const int ld_row = lane / G_::PIECES, ld_piece = lane % G_::PIECES;
     uint32_t krd0[2], trd0[4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) krd0[s] = rho * G_::ROWB + (((4 * s + q) ^ G_::swz_k(rho)) << 4);
@@ -529,7 +568,7 @@ static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
     const size_t lds = 4 * (size_t)(2 * Geo<64>::TILE_BYTES);
     if (split) {
         const int64_t waves = nbg * ngrp * P.nsplit;
-        hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st, P);
+        hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, true, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st, P);
         NSA_LAUNCH_CHECK("band_attn_fwd(split)");
         if (P.defer_combine) return NSA_OK;
         SelAttnParams C{};
@@ -547,8 +586,11 @@ static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
     P.map_mode = (nbg % 8 == 0) ? 2 : 1;
     NSA_CHECK_ARG(nbg * W < ((int64_t)1 << 31), "band_attn: too many workgroups for one launch");
     const unsigned grid = (unsigned)(nbg * W);
-    if (nt == 3) hipLaunchKernelGGL((band_attn_fwd_kernel<T, 3, false>), dim3(grid), dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, false>), dim3(grid), dim3(256), lds, st, P);
+    const char *se = getenv("NSA_HIP_BAND_STAGE");  // A/B switch: 0 = register staging, 1 = LDS-DMA
+    const int stage = se ? atoi(se) : 1;  // measured: LDS-DMA 750 vs register staging 650 TFLOP/s (compressed branch, 64k)
+    if (nt == 3 && stage == 0) hipLaunchKernelGGL((band_attn_fwd_kernel<T, 3, false, 0>), dim3(grid), dim3(256), lds, st, P);
+    else if (nt == 3) hipLaunchKernelGGL((band_attn_fwd_kernel<T, 3, false, 1>), dim3(grid), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, false, 1>), dim3(grid), dim3(256), lds, st, P);
     NSA_LAUNCH_CHECK("band_attn_fwd");
     return NSA_OK;
 }

@@ -11,7 +11,7 @@ import sys
 
 src, key = sys.argv[1], sys.argv[2]
 minlen = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]
 subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", "--cuda-device-only", src, "-o", "/tmp/isa_loop.s"], check=True,
                stderr=subprocess.DEVNULL)
 s = open("/tmp/isa_loop.s").read().split("\n")

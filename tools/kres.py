@@ -3,7 +3,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
-                      "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+                      "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
