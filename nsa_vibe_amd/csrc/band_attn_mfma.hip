@@ -19,13 +19,13 @@ namespace nsa {
 
 // STAGE 1: tiles come by LDS-DMA; STAGE 0: register staging (global loads issued behind the fragment reads, ds_write at the top of the
 // next iteration): the compute-bound NT = 3 form spends ~19 % of a tile issuing its 8 DMA instructions, plain loads issue faster.
-template <typename T, int NT, bool SPLIT, int STAGE>
+template <typename T, int D, int NT, bool SPLIT, int STAGE>
 __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const unsigned bid) {
     using M = MfmaT<T>;
-    using G_ = Geo<64>;
+    using G_ = Geo<D>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
-    constexpr int D = 64;
+    constexpr int KS = G_::KSTEPS, MT = G_::MT;  // QK k-steps, 16-row dv tiles of PV
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
     const int wave = uniform((int)(threadIdx.x >> 6));
@@ -67,7 +67,7 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
     const int rho = lane & 15, q = lane >> 4;
     int hi_s[NT], lo_s[NT];
     int64_t orow[NT];  // (row * h + head) of the slot, -1 = unused slot
-    x8 qf[NT][2];
+    x8 qf[NT][KS];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int slot = 16 * n + rho, tok = slot / h, head = slot - tok * h;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         lo_s[n] = max(0, hi_s[n] - P.w);
         orow[n] = used ? ((((int64_t)b * P.S + t) * P.G + g) * h + head) : -1;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             u32x4 raw = {0u, 0u, 0u, 0u};
             if (used) raw = *(const u32x4 *)((const T *)P.Q + orow[n] * D + 32 * s + 8 * q);
             qf[n][s] = __builtin_bit_cast(x8, raw);
@@ -105,13 +105,13 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         kdma[i] = (uint32_t)(ld_row * krowb + ((ld_piece ^ G_::swz_k(r)) << 4));
         vdma[i] = (uint32_t)(ld_row * vrowb + (((((ld_piece >> 1) ^ G_::swz_v(r)) << 1) | (ld_piece & 1)) << 4));
     }
-    uint32_t krd0[2], vrd0[4];
+    uint32_t krd0[KS], vrd0[MT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) krd0[s] = rho * G_::ROWB + (((4 * s + q) ^ G_::swz_k(rho)) << 4);
+    for (int s = 0; s < KS; ++s) krd0[s] = rho * G_::ROWB + (((4 * s + q) ^ G_::swz_k(rho)) << 4);
     {
         const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) vrd0[m] = r * G_::ROWB + ((m ^ G_::swz_v(r)) << 5) + 8 * pp;
+        for (int m = 0; m < MT; ++m) vrd0[m] = r * G_::ROWB + ((m ^ G_::swz_v(r)) << 5) + 8 * pp;
     }
     // a tile of 32 keys starting at tok0 -> wave-private LDS (swizzle applied on the source side); rows past the end of
     // K/V re-read the last row (they are masked: only boundary tiles reach past hi)
@@ -162,12 +162,12 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         }
     };
 
-    f32x4 o[NT][4];
+    f32x4 o[NT][MT];
     float mrun[NT], lrun[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) o[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MT; ++m) o[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // unused slots carry +inf so that their (zero) scores never trigger the max-raising path
         mrun[n] = orow[n] >= 0 ? -INFINITY : INFINITY;
         lrun[n] = 0.f;
@@ -188,8 +188,8 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
 
     for (; tile < tile_end; ++tile) {
         const int tok0 = klo + 32 * tile;
-        x8 kfr[2][2];
-        x8 va[4];
+        x8 kfr[2][KS];
+        x8 va[MT];
         if (STAGE == 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is a vmcnt event
         } else {
@@ -203,9 +203,9 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) kfr[u][s] = *(const x8 *)(kl + krd0[s] + u * 16 * G_::ROWB);
+            for (int s = 0; s < KS; ++s) kfr[u][s] = *(const x8 *)(kl + krd0[s] + u * 16 * G_::ROWB);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const x4 lo = M::tr(vl + vrd0[m]), hi = M::tr(vl + vrd0[m] + 16 * G_::ROWB);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
             for (int u = 0; u < 2; ++u) {
                 sacc[n][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) sacc[n][u] = M::mma(kfr[u][s], qf[n][s], sacc[n][u]);
+                for (int s = 0; s < KS; ++s) sacc[n][u] = M::mma(kfr[u][s], qf[n][s], sacc[n][u]);
             }
         // key of sacc[n][u][j] = tok0 + 16u + 4q + j
         float x[NT][8];
@@ -268,7 +268,7 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
                 mrun[n] = mnew;
                 lrun[n] *= alpha;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) o[n][m] *= alpha;
+                for (int m = 0; m < MT; ++m) o[n][m] *= alpha;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[n][j] -= msub;
             }
@@ -285,7 +285,7 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
             }
             lrun[n] += psum;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) o[n][m] = M::mma(va[m], pf, o[n][m]);
+            for (int m = 0; m < MT; ++m) o[n][m] = M::mma(va[m], pf, o[n][m]);
         }
     }
 
@@ -305,12 +305,12 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
                 pr[1] = ltot;
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) *(f32x4 *)(pr + PART_PAD + 16 * m + 4 * q) = o[n][m];
+            for (int m = 0; m < MT; ++m) *(f32x4 *)(pr + PART_PAD + 16 * m + 4 * q) = o[n][m];
         } else {
             const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
             T *Or = (T *)P.O + orow[n] * D;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 x4 ov;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ov[j] = Elt<T>::from_f(o[n][m][j] * inv);
@@ -321,16 +321,16 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
     }
 }
 
-template <typename T, int NT, bool SPLIT, int STAGE>
+template <typename T, int D, int NT, bool SPLIT, int STAGE>
 __global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
-    band_attn_body<T, NT, SPLIT, STAGE>(P, blockIdx.x);
+    band_attn_body<T, D, NT, SPLIT, STAGE>(P, blockIdx.x);
 }
 
 // decode: the sliding and the compressed branch of one step in ONE launch (two argument blocks, split-KV form)
-template <typename T>
+template <typename T, int D>
 __global__ __launch_bounds__(256) void band_attn_fwd_dual_kernel(BandAttnParams P0, BandAttnParams P1, unsigned grid0) {
-    if (blockIdx.x < grid0) band_attn_body<T, 1, true, 1>(P0, blockIdx.x);
-    else band_attn_body<T, 1, true, 1>(P1, blockIdx.x - grid0);
+    if (blockIdx.x < grid0) band_attn_body<T, D, 1, true, 1>(P0, blockIdx.x);
+    else band_attn_body<T, D, 1, true, 1>(P1, blockIdx.x - grid0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -527,16 +527,18 @@ __global__ __launch_bounds__(256) void band_attn_bwd_dq_kernel(BandAttnParams P,
 
 // ---- host side ----------------------------------------------------------------------------
 bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv) {
-    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == Dv && (Dk == 64 || Dk == 128) && h >= 1 && h <= 16;
 }
 
 // NT = 3 column tiles per wave (48 / h tokens) once there are enough tokens to fill the chip, NT = 1 (16 / h tokens)
 // below that; with very few token groups (decode) the key interval is also split over several waves.
-static void band_plan(int B, int S, int G, int h, int *nt, int *tpw, int *nsplit) {
-    const int tpw3 = 48 / h, tpw1 = 16 / h;
+// (D = 128: 2 column tiles, the accumulators are twice as wide)
+static void band_plan(int B, int S, int G, int h, int D, int *nt, int *tpw, int *nsplit) {
+    const int ntw = D == 64 ? 3 : 2;
+    const int tpw3 = 16 * ntw / h, tpw1 = 16 / h;
     const int64_t grp3 = (int64_t)B * G * ((S + tpw3 - 1) / tpw3);
     if (grp3 >= 2048) {
-        *nt = 3, *tpw = tpw3, *nsplit = 1;
+        *nt = ntw, *tpw = tpw3, *nsplit = 1;
         return;
     }
     *nt = 1, *tpw = tpw1;
@@ -551,24 +553,24 @@ static void band_plan(int B, int S, int G, int h, int *nt, int *tpw, int *nsplit
 
 size_t band_attn_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int *nsplit_out) {
     int nt = 1, tpw = 1, ns = 1;
-    if (band_attn_mfma_supported(dtype, h, Dk, Dv)) band_plan(B, S, G, h, &nt, &tpw, &ns);
+    if (band_attn_mfma_supported(dtype, h, Dk, Dv)) band_plan(B, S, G, h, Dk, &nt, &tpw, &ns);
     if (nsplit_out) *nsplit_out = ns;
     return ns > 1 ? (size_t)B * S * G * ns * h * (Dv + PART_PAD) * sizeof(float) : 0;
 }
 
-template <typename T>
+template <typename T, int D>
 static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
     BandAttnParams P = P0;
     int nt = 1, ns = 1;
-    band_plan(P.B, P.S, P.G, P.h, &nt, &P.tpw, &ns);
+    band_plan(P.B, P.S, P.G, P.h, D, &nt, &P.tpw, &ns);
     const bool split = ns > 1 && P.part != nullptr && P.nsplit == ns;
     if (!split) P.nsplit = 1;
     const int64_t nbg = (int64_t)P.B * P.G;
     const int ngrp = (P.S + P.tpw - 1) / P.tpw;
-    const size_t lds = 4 * (size_t)(2 * Geo<64>::TILE_BYTES);
+    const size_t lds = 4 * (size_t)(2 * Geo<D>::TILE_BYTES);
     if (split) {
         const int64_t waves = nbg * ngrp * P.nsplit;
-        hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, true, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st, P);
+        hipLaunchKernelGGL((band_attn_fwd_kernel<T, D, 1, true, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st, P);
         NSA_LAUNCH_CHECK("band_attn_fwd(split)");
         if (P.defer_combine) return NSA_OK;
         SelAttnParams C{};
@@ -578,7 +580,7 @@ static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
         C.h = P.h;
         C.part = P.part;
         C.nsplit = P.nsplit;
-        hipLaunchKernelGGL((sel_attn_combine_kernel<T, 64>), dim3((unsigned)((C.R * C.h + 3) / 4)), dim3(256), 0, st, C);
+        hipLaunchKernelGGL((sel_attn_combine_kernel<T, D>), dim3((unsigned)((C.R * C.h + 3) / 4)), dim3(256), 0, st, C);
         NSA_LAUNCH_CHECK("band_attn_combine");
         return NSA_OK;
     }
@@ -588,9 +590,17 @@ static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
     const unsigned grid = (unsigned)(nbg * W);
     const char *se = getenv("NSA_HIP_BAND_STAGE");  // A/B switch: 0 = register staging, 1 = LDS-DMA
     const int stage = se ? atoi(se) : 1;  // measured: LDS-DMA 750 vs register staging 650 TFLOP/s (compressed branch, 64k)
-    if (nt == 3 && stage == 0) hipLaunchKernelGGL((band_attn_fwd_kernel<T, 3, false, 0>), dim3(grid), dim3(256), lds, st, P);
-    else if (nt == 3) hipLaunchKernelGGL((band_attn_fwd_kernel<T, 3, false, 1>), dim3(grid), dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((band_attn_fwd_kernel<T, 1, false, 1>), dim3(grid), dim3(256), lds, st, P);
+    constexpr int NTW = D == 64 ? 3 : 2;
+    bool done = false;
+    if constexpr (D == 64) {
+        if (nt == NTW && stage == 0) {
+            hipLaunchKernelGGL((band_attn_fwd_kernel<T, D, NTW, false, 0>), dim3(grid), dim3(256), lds, st, P);
+            done = true;
+        }
+    }
+    if (done) {
+    } else if (nt == NTW) hipLaunchKernelGGL((band_attn_fwd_kernel<T, D, NTW, false, 1>), dim3(grid), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((band_attn_fwd_kernel<T, D, 1, false, 1>), dim3(grid), dim3(256), lds, st, P);
     NSA_LAUNCH_CHECK("band_attn_fwd");
     return NSA_OK;
 }
@@ -604,8 +614,8 @@ int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st
                   "band MFMA kernel: Q/K/V must be 16-byte aligned");
     NSA_CHECK_ARG((int64_t)P.S_kv * P.kss * 2 < ((int64_t)1 << 31) && (int64_t)P.S_kv * P.vss * 2 < ((int64_t)1 << 31),
                   "band MFMA kernel: one (b,g) K/V slab must be smaller than 2 GiB (buffer addressing)");
-    if (dtype == NSA_DT_BF16) return launch_band_t<__bf16>(P, st);
-    return launch_band_t<_Float16>(P, st);
+    if (dtype == NSA_DT_BF16) return P.Dk == 64 ? launch_band_t<__bf16, 64>(P, st) : launch_band_t<__bf16, 128>(P, st);
+    return P.Dk == 64 ? launch_band_t<_Float16, 64>(P, st) : launch_band_t<_Float16, 128>(P, st);
 }
 
 // Both branches of a decode step in one launch.  Requires both to be in split form with deferred combine (the caller combines).
@@ -614,14 +624,22 @@ int launch_band_attn_fwd_dual(const BandAttnParams &A0, const BandAttnParams &A1
     unsigned grid[2];
     for (int i = 0; i < 2; ++i) {
         int nt = 1, ns = 1;
-        band_plan(P[i].B, P[i].S, P[i].G, P[i].h, &nt, &P[i].tpw, &ns);
+        band_plan(P[i].B, P[i].S, P[i].G, P[i].h, P[i].Dk, &nt, &P[i].tpw, &ns);
         NSA_CHECK_ARG(nt == 1 && ns > 1 && P[i].part && P[i].nsplit == ns && P[i].defer_combine, "band dual launch: split form required");
         const int64_t waves = (int64_t)P[i].B * P[i].G * ((P[i].S + P[i].tpw - 1) / P[i].tpw) * ns;
         grid[i] = (unsigned)((waves + 3) / 4);
     }
-    const size_t lds = 4 * (size_t)(2 * Geo<64>::TILE_BYTES);
-    if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(band_attn_fwd_dual_kernel<__bf16>, dim3(grid[0] + grid[1]), dim3(256), lds, st, P[0], P[1], grid[0]);
-    else hipLaunchKernelGGL(band_attn_fwd_dual_kernel<_Float16>, dim3(grid[0] + grid[1]), dim3(256), lds, st, P[0], P[1], grid[0]);
+    NSA_CHECK_ARG(P[0].Dk == P[1].Dk && band_attn_mfma_supported(dtype, P[0].h, P[0].Dk, P[0].Dv), "band dual launch: unsupported shape");
+    const bool d64 = P[0].Dk == 64;
+    const size_t lds = 4 * (size_t)(2 * (d64 ? Geo<64>::TILE_BYTES : Geo<128>::TILE_BYTES));
+    const dim3 g2(grid[0] + grid[1]);
+    if (dtype == NSA_DT_BF16) {
+        if (d64) hipLaunchKernelGGL((band_attn_fwd_dual_kernel<__bf16, 64>), g2, dim3(256), lds, st, P[0], P[1], grid[0]);
+        else hipLaunchKernelGGL((band_attn_fwd_dual_kernel<__bf16, 128>), g2, dim3(256), lds, st, P[0], P[1], grid[0]);
+    } else {
+        if (d64) hipLaunchKernelGGL((band_attn_fwd_dual_kernel<_Float16, 64>), g2, dim3(256), lds, st, P[0], P[1], grid[0]);
+        else hipLaunchKernelGGL((band_attn_fwd_dual_kernel<_Float16, 128>), g2, dim3(256), lds, st, P[0], P[1], grid[0]);
+    }
     NSA_LAUNCH_CHECK("band_attn_fwd_dual");
     return NSA_OK;
 }
@@ -647,7 +665,7 @@ static int launch_band_dq_t(BandAttnParams P, const BandBwdExtra &E, hipStream_t
 
 int launch_band_attn_bwd_dq(const BandAttnParams &P, const void *dO, const float *lse, const float *delta, void *dQ, int dtype,
                             hipStream_t st) {
-    NSA_CHECK_ARG(band_attn_mfma_supported(dtype, P.h, P.Dk, P.Dv), "band dQ kernel: unsupported dtype/h/Dk/Dv");
+    NSA_CHECK_ARG(band_attn_mfma_supported(dtype, P.h, P.Dk, P.Dv) && P.Dk == 64, "band dQ kernel: unsupported dtype/h/Dk/Dv");
     BandBwdExtra E{dO, lse, delta, dQ};
     if (dtype == NSA_DT_BF16) return launch_band_dq_t<__bf16>(P, E, st);
     return launch_band_dq_t<_Float16>(P, E, st);

@@ -165,3 +165,22 @@ def test_backward_dense_dq_kernel_vs_oracle(nv, orc, band, B, S, G):
         assert np.isfinite(g).all(), name
         err = np.abs(g - ref).max()
         assert err <= 2e-2 * max(1.0, np.abs(ref).max()), f"{name}: {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,S,G,h,band", [(2, 3000, 2, 6, dict(w=512)), (1, 5000, 8, 2, dict(a=32, dd=16, c=1)), (1, 900, 1, 16, dict(w=64)),
+                                          (3, 300, 2, 5, dict(w=77))])
+def test_band_mfma_head_dim_128(nv, orc, dtype, B, S, G, h, band):
+    """D = 128: 2 column tiles per wave (32 slots) once there are enough token groups, the 16-slot kernel below that"""
+    S_kv = S if "w" in band else (S - 32) // 16 + 1
+    Q, K, V = rand_qkv(2100 + S + h, B, S, G, h, 128, 128, S_kv)
+    check(nv, orc, Q, K, V, dtype, 2, band)
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_decode_rows_head_dim_128(nv, orc, B):
+    G, h, t0 = 2, 4, 3000
+    Q, K, V = rand_qkv(2200 + B, B, 1, G, h, 128, 128, t0 + 1)
+    check(nv, orc, Q, K, V, torch.bfloat16, 2, dict(t0=t0, w=512))
+    n_cmp = (t0 + 1 - 32) // 16 + 1
+    check(nv, orc, Q, K[:, :, :n_cmp], V[:, :, :n_cmp], torch.bfloat16, 2, dict(t0=t0, a=32, dd=16, c=1))
