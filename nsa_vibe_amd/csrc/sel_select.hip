@@ -101,7 +101,7 @@ int batched_width(int S, int S_sel, int l_sel, int n_top, int force_init, int fo
 }
 
 int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, int force_init, int force_local, int W) {
-    NSA_CHECK_ARG(S_sel >= 1 && S_sel <= 64 * 32 && l_sel >= 1 && n_top >= 0 && force_local >= 0 && force_local <= 30 && W == n_top,
+    NSA_CHECK_ARG(S_sel >= 1 && S_sel <= 64 * 64 && l_sel >= 1 && n_top >= 0 && force_local >= 0 && force_local <= 30 && W == n_top,
                   "select (sequential): bad sizes");
     P->S_sel = S_sel; P->l_sel = l_sel; P->n_top = n_top; P->force_init = force_init ? 1 : 0; P->force_local = force_local;
     P->mode = NSA_SEL_SEQUENTIAL; P->W = W;
@@ -116,7 +116,7 @@ int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, i
 
 int select_params_fill(SelectParams *Pp, int S_sel, int l_sel, int n_top, int force_init, int force_local, int mode, int S_total, int W) {
     SelectParams &P = *Pp;
-    NSA_CHECK_ARG(S_sel >= 1 && S_sel <= 64 * 32 && l_sel >= 1 && n_top >= 0 && force_local >= 0 && force_local <= 30, "select: bad sizes");
+    NSA_CHECK_ARG(S_sel >= 1 && S_sel <= 64 * 64 && l_sel >= 1 && n_top >= 0 && force_local >= 0 && force_local <= 30, "select: bad sizes");
     P.S_sel = S_sel; P.l_sel = l_sel; P.n_top = n_top; P.force_init = force_init ? 1 : 0; P.force_local = force_local; P.mode = mode; P.W = W;
     const int nf_all = P.force_init + force_local;
     if (mode == NSA_SEL_SEQUENTIAL) {
@@ -145,7 +145,7 @@ int launch_select_topn(const float *p_grp, int64_t R, int S, int G, int t0, cons
                        int l_sel, int n_top, int force_init, int force_local, int mode, int S_total,
                        int32_t *out, int W, hipStream_t st) {
     NSA_CHECK_ARG(R >= 0 && S >= 1 && G >= 1 && S_sel >= 1 && l_sel >= 1 && n_top >= 0, "select: bad sizes");
-    NSA_CHECK_ARG(S_sel <= 64 * 32, "select: S_sel=%d exceeds 2048 selection blocks", S_sel);
+    NSA_CHECK_ARG(S_sel <= 64 * 64, "select: S_sel=%d exceeds 4096 selection blocks", S_sel);
     NSA_CHECK_ARG(force_local >= 0 && force_local <= 30, "select: force_local out of range");
     SelectParams P{};
     P.p_grp = p_grp; P.t_rows = t_rows; P.out = out; P.R = R; P.S = S; P.G = G; P.t0 = t0; P.S_sel = S_sel;
@@ -161,7 +161,8 @@ int launch_select_topn(const float *p_grp, int64_t R, int S, int G, int t0, cons
     else if (cand <= 4) NSA_SEL_LAUNCH(4);
     else if (cand <= 8) NSA_SEL_LAUNCH(8);
     else if (cand <= 16) NSA_SEL_LAUNCH(16);
-    else NSA_SEL_LAUNCH(32);
+    else if (cand <= 32) NSA_SEL_LAUNCH(32);
+    else NSA_SEL_LAUNCH(64);
 #undef NSA_SEL_LAUNCH
     NSA_LAUNCH_CHECK("select_topn");
     return NSA_OK;

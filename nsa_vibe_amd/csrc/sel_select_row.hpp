@@ -25,14 +25,14 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     const int nvalid_blocks = min(S_sel, (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
 
     float key[CAND];
-    unsigned selbits = 0;  // bit c = block lane + 64 c selected
+    unsigned long long selbits = 0ull;  // bit c = block lane + 64 c selected
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
         const int j = lane + 64 * c;
         float k = -INFINITY;
         if (j < nvalid_blocks) k = __fsub_rn(p[j], __fmul_rn((float)j, 1e-8f));
         key[c] = k;
-        if (P.all_valid && j < nvalid_blocks) selbits |= 1u << c;
+        if (P.all_valid && j < nvalid_blocks) selbits |= 1ull << c;
     }
 
     if (!P.all_valid) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                 for (int cc = 0; cc < CAND; ++cc)
                     if (cc == c) {
                         key[cc] = -INFINITY;                                              // excluded from top-k
-                        if (P.mode == NSA_SEL_SEQUENTIAL || valid) selbits |= 1u << cc;   // batched drops invalid picks
+                        if (P.mode == NSA_SEL_SEQUENTIAL || valid) selbits |= 1ull << cc;   // batched drops invalid picks
                     }
             }
         }
@@ -95,7 +95,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                 const bool eq = u[c] == T;
                 const unsigned long long em = __ballot(eq);
                 const int take = min(__popcll(em), remaining);
-                if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1u << c;
+                if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1ull << c;
                 remaining -= take;
             }
         }
@@ -115,7 +115,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     };
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
-        unsigned long long w = __ballot((selbits >> c) & 1u);
+        unsigned long long w = __ballot((selbits >> c) & 1ull);
         while (w) {  // maximal runs of ones of this word, ascending
             const int sb = __builtin_ctzll(w);
             const unsigned long long inv = ~(w >> sb);

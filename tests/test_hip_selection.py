@@ -343,3 +343,21 @@ def test_beyond_64k_selection_matches_oracle(nv, orc):
     r2, O = nv.select_and_attend(p, Q, K, V, m, n, mode="batched")
     assert torch.equal(r2, r) and torch.isfinite(O).all()
     assert torch.equal(O, nv.selection_attention_hip(Q, K, V, r))
+
+
+def test_262144_tokens_selector(nv, orc):
+    """S = 262144 (S_sel = 4096, 64 candidates per lane): sequential selection of sampled decode positions bit-exact vs the oracle"""
+    import torch
+
+    S, n = 262144, 16
+    m = nv.build_block_meta(S, 32, 16, 64, n, 512)
+    om = orc.build_block_meta(S, 32, 16, 64, n, 512)
+    assert m.S_sel == 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    for t in (262143, 200000, 131072, 131071, 70001):
+        p = torch.rand(2, 3, m.S_sel, device="cuda", generator=g)
+        p[:, :, ::5] = 0.125  # ties
+        r = nv.select_topn_ranges(p, m, n, t).cpu().numpy()
+        ref = orc.select_topn_ranges(p.cpu().numpy(), om, n, t)
+        assert orc.normalise_ranges(r) == orc.normalise_ranges(ref), t
