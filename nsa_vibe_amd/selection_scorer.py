@@ -14,7 +14,7 @@ from . import _lib
 from .block_index import BlockMeta
 
 _DT = {torch.float32: _lib.NSA_DT_F32, torch.bfloat16: _lib.NSA_DT_BF16, torch.float16: _lib.NSA_DT_F16}
-_WS: Dict[str, torch.Tensor] = {}
+_WS: Dict[tuple, torch.Tensor] = {}
 
 
 def _need_gpu(*ts: torch.Tensor) -> torch.device:
@@ -32,11 +32,11 @@ def _stream(dev: torch.device) -> int:
 
 
 def workspace(dev: torch.device, nbytes: int, tag: str = "ws") -> Optional[torch.Tensor]:
-    """Grow-on-demand per-device scratch (the reference keeps process-global workspaces too,
-    nsa/core/attention_kernels.py:25-26,64-103)."""
+    """Grow-on-demand scratch per (device, stream) (the reference keeps process-global workspaces too,
+    nsa/core/attention_kernels.py:25-26,64-103; keyed by stream here so concurrent streams cannot race on it)."""
     if nbytes <= 0:
         return None
-    key = f"{tag}:{dev}"
+    key = (tag, dev.index, torch.cuda.current_stream(dev).cuda_stream)  # per stream: two streams never share scratch
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
