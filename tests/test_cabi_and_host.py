@@ -180,3 +180,20 @@ def test_two_rank_gloo_sharding(tmp_path):
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["tmax"] == 2.0 and res["nsum"] == 5.0
     assert res["pairs"] == [[b, g] for b in range(5) for g in range(2)]
+
+
+def test_llama_block_state_dict_matches_reference():
+    """LlamaBlockNSA / NSAAttention parameter names and shapes = the reference's (nsa/model/llama_block_nsa.py:33-63), so its
+    checkpoints load unchanged (golden written from the imported reference module)"""
+    import json
+    import os
+
+    from nsa_vibe_amd.llama_block_nsa import LlamaBlockNSA, TinyLM
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g14_llama_block_state_dict.json")))
+    blk = LlamaBlockNSA(**g["args"])
+    mine = {k: list(v.shape) for k, v in blk.state_dict().items()}
+    assert mine == g["state_dict"]
+    lm = TinyLM(100, 64, 2, 4, 2, 16, 16, 8, 4, 8, 4, 16)
+    keys = set(lm.state_dict().keys())
+    assert {"embed.weight", "norm_f.weight", "lm_head.weight", "blocks.0.attn.W_Q.weight", "blocks.1.mlp.fc2.weight"} <= keys

@@ -394,3 +394,21 @@ def test_layer_trains_under_ddp_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_tiny_lm_prefill_decode_consistency():
+    """TinyLM (embed -> LlamaBlockNSA x 3 -> norm -> head): logits of token S from prefill(S) + decode(1) equal the last-token
+    logits of prefill(S + 1) (fp32), and the reference-style forward(tokens) gives the same logits as the cached prefill"""
+    from nsa_vibe_amd.llama_block_nsa import TinyLM
+
+    torch.manual_seed(2)
+    lm = TinyLM(97, 64, 3, 4, 2, 16, 16, 8, 4, 8, 4, 16, selector="sequential").cuda().float().eval()
+    B, S = 2, 60
+    tok = torch.randint(0, 97, (B, S + 1), device="cuda")
+    with torch.no_grad():
+        full = lm.prefill(tok, lm.new_caches(B, S + 1, "cuda", torch.float32), last_only=False)
+        assert (full - lm(tok)).abs().max().item() <= 1e-4
+        caches = lm.new_caches(B, S + 1, "cuda", torch.float32)
+        lm.prefill(tok[:, :S], caches)
+        step = lm.decode(tok[:, S:], caches)
+    assert (step[:, 0] - full[:, S]).abs().max().item() <= 2e-4
