@@ -153,8 +153,11 @@ typedef struct nsa_kv_desc {
     int B, S_max, n_cmp_max;
 } nsa_kv_desc;
 
-/* out[M,N] = A[M,K] . W[N,K]^T for few rows (decode projections). */
-NSA_API int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, void *stream);
+/* out[M,N] = epilogue(A[M,K] . W[N,K]^T) for few rows (decode projections).  epilogue 0: none, 1: silu, 2: + residual[M,N]. */
+NSA_API int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epilogue, const void *residual,
+                     void *stream);
+/* y[M,dim] = RMSNorm(x) * w for few rows (llama_block_nsa.py:10-19). */
+NSA_API int nsa_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, void *stream);
 /* RoPE (Q over the flattened head axis, K_sel/K_win per group; nsa_attention.py:552-572, 1002-1024) on a fused projection
  * proj [B,S,NQ+3GDk+3GDv] and append of the S tokens at cache position t0: Q_out [B,S,G,h,Dk]. */
 NSA_API int nsa_rope_cache_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, void *Q_out, int S, int t0,
@@ -177,6 +180,22 @@ NSA_API int nsa_cmp_pool_bwd(const nsa_layer_desc *L, int B, int S, int n_cmp, c
                      void *dV_raw, void *stream);
 NSA_API int nsa_gate_combine_bwd(const nsa_layer_desc *L, const void *dO, const void *O_cmp, const void *O_sel, const void *O_win,
                          const float *gates, void *dO_cmp, void *dO_sel, void *dO_win, float *dgates, int64_t R, void *stream);
+/* One decode step of a whole LlamaBlockNSA (nsa/model/llama_block_nsa.py:33-106: x + attn(norm1(x)), then + mlp(norm2(.))) in one
+ * call: RMSNorm -> nsa_layer_decode_step with the residual added in the output projection's epilogue -> RMSNorm -> fc1 + silu ->
+ * fc2 + residual.  x, y [B,dim]; the MLP weights are row-major [out,in] like nn.Linear. */
+typedef struct nsa_block_desc {
+    nsa_layer_desc attn;
+    const void *norm1_w, *norm2_w; /* [dim] */
+    const void *mlp_w1;            /* [mlp_hidden, dim] */
+    const void *mlp_w2;            /* [dim, mlp_hidden] */
+    int mlp_hidden;
+    float norm_eps;
+} nsa_block_desc;
+NSA_API size_t nsa_block_decode_step_workspace(const nsa_block_desc *Bk, int B, int S_max);
+NSA_API int nsa_block_decode_step(const nsa_block_desc *Bk, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
+                          const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* Prefill of the whole layer between the two big GEMMs, in one call (nsa_attention.py:978-1448 / 1521-1723): proj [B,S,NQ+3GDk+3GDv]
  * (= x @ W_qkv^T) -> RoPE + append of the S tokens into the EMPTY caches -> compressed-token pooling -> selection scores ->
  * top-n + selection attention -> sliding and compressed branches -> gates + combine -> O_mix [B,S,G*h*Dv] (input of the output

@@ -33,7 +33,13 @@ class NsaKvDesc(C.Structure):
                [(n, _i) for n in ("B", "S_max", "n_cmp_max")]
 
 
-_pl, _pk = C.POINTER(NsaLayerDesc), C.POINTER(NsaKvDesc)
+class NsaBlockDesc(C.Structure):
+    """struct nsa_block_desc (include/nsa_sel_hip.h)"""
+    _fields_ = [("attn", NsaLayerDesc), ("norm1_w", _vp), ("norm2_w", _vp), ("mlp_w1", _vp), ("mlp_w2", _vp), ("mlp_hidden", _i),
+                ("norm_eps", _f)]
+
+
+_pl, _pk, _pb = C.POINTER(NsaLayerDesc), C.POINTER(NsaKvDesc), C.POINTER(NsaBlockDesc)
 
 # name -> (restype, argtypes); mirrors include/nsa_sel_hip.h one to one
 SIGNATURES = {
@@ -46,7 +52,10 @@ SIGNATURES = {
     "nsa_sel_attn_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_band_attn_fwd_workspace": (_sz, [_i] * 7),
     "nsa_band_attn_fwd": (_i, [_vp] * 5 + [_i] * 7 + [_i64] * 6 + [_i] * 5 + [_i, _f, _i, _vp, _sz, _vp]),
-    "nsa_linear_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nsa_linear_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "nsa_rmsnorm_rows": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "nsa_block_decode_step_workspace": (_sz, [_pb, _i, _i]),
+    "nsa_block_decode_step": (_i, [_pb, _pk, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nsa_rope_cache_append": (_i, [_pl, _pk, _vp, _vp, _i, _i, _vp]),
     "nsa_cmp_pool_append": (_i, [_pl, _pk, _i, _i, _vp]),
     "nsa_gate_combine": (_i, [_pl, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -57,8 +57,16 @@ __device__ __forceinline__ void load8(const T *p, int nvalid, bool vec, float (&
 
 // one wave per output column n (W row n stays in registers), rows of A in chunks of 8
 template <typename T>
+__device__ __forceinline__ float linear_epilogue(float acc, int epi, const T *res, int64_t idx) {
+    float v = rnd<T>(acc);  // the GEMM result in the activation dtype, then the fused elementwise op rounds again like the eager chain
+    if (epi == 1) v = rnd<T>(v / (1.f + expf(-v)));       // silu
+    else if (epi == 2) v = v + Elt<T>::to_f(res[idx]);  // + residual
+    return v;
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M,
-                                                           int N, int K) {
+                                                           int N, int K, int epi, const T *__restrict__ res) {
     const int lane = lane_id();
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -78,21 +86,23 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__
         }
         for (int r = 0; r < mm; ++r) {
             const float s = wave_sum(acc[r]);
-            if (lane == 0) out[(int64_t)(m0 + r) * N + n] = Elt<T>::from_f(s);
+            if (lane == 0) out[(int64_t)(m0 + r) * N + n] = Elt<T>::from_f(linear_epilogue<T>(s, epi, res, (int64_t)(m0 + r) * N + n));
         }
     }
 }
 
 template <typename T>
-static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t st) {
-    hipLaunchKernelGGL(linear_small_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K);
+static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, int epi, const void *res, hipStream_t st) {
+    hipLaunchKernelGGL(linear_small_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K, epi,
+                       (const T *)res);
     NSA_LAUNCH_CHECK("linear_small");
     return NSA_OK;
 }
-static int launch_linear_small_valu(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
-    if (dtype == NSA_DT_F32) return linear_small_t<float>(A, W, out, M, N, K, st);
-    if (dtype == NSA_DT_BF16) return linear_small_t<__bf16>(A, W, out, M, N, K, st);
-    return linear_small_t<_Float16>(A, W, out, M, N, K, st);
+static int launch_linear_small_valu(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res,
+                                    hipStream_t st) {
+    if (dtype == NSA_DT_F32) return linear_small_t<float>(A, W, out, M, N, K, epi, res, st);
+    if (dtype == NSA_DT_BF16) return linear_small_t<__bf16>(A, W, out, M, N, K, epi, res, st);
+    return linear_small_t<_Float16>(A, W, out, M, N, K, epi, res, st);
 }
 
 // ------------------------------------------------------------------------------------------ RoPE + cache append
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P
 // K-partials meet in LDS.  Thread t of the epilogue owns row m = t % 64 and columns 4 (t / 64) .. +3 (two rotation pairs).
 template <typename T, bool ROPE>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
-                                                          T *__restrict__ out, int M, int N, int K) {
+                                                          T *__restrict__ out, int M, int N, int K, int epi, const T *__restrict__ res) {
     using MT_ = MfmaT<T>;
     using x8 = typename MT_::x8;
     __shared__ float part[4][16][65];
@@ -359,7 +369,10 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, co
         for (int p = 0; p < 2; ++p) rope_store_pair<T>(P, m, 0, n0 + 4 * nq + 2 * p, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(int64_t)m * N + n0 + 4 * nq + r] = Elt<T>::from_f(v[r]);
+        for (int r = 0; r < 4; ++r) {
+            const int64_t idx = (int64_t)m * N + n0 + 4 * nq + r;
+            out[idx] = Elt<T>::from_f(linear_epilogue<T>(v[r], epi, res, idx));
+        }
     }
 }
 
@@ -368,24 +381,27 @@ static bool linear_mfma_ok(int dtype, int M, int N, int K, const void *X, const 
            (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
 }
 
-int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
+int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, hipStream_t st) {
     if (linear_mfma_ok(dtype, M, N, K, A, W)) {
         RopeAppendParams P{};
         const dim3 g2((unsigned)(N / 16), (unsigned)((M + 63) / 64));
-        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K);
-        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K);
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res);
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res);
         NSA_LAUNCH_CHECK("linear_small(mfma)");
         return NSA_OK;
     }
-    return launch_linear_small_valu(A, W, out, M, N, K, dtype, st);
+    return launch_linear_small_valu(A, W, out, M, N, K, dtype, epi, res, st);
+}
+int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
+    return launch_linear_small_epi(A, W, out, M, N, K, dtype, 0, nullptr, st);
 }
 
 int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st) {
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
     if (linear_mfma_ok(dtype, P.B, NT, K, X, W)) {
         const dim3 g2((unsigned)(NT / 16), (unsigned)((P.B + 63) / 64));
-        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K);
-        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K);
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K, 0, (const __bf16 *)nullptr);
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K, 0, (const _Float16 *)nullptr);
         NSA_LAUNCH_CHECK("qkv_rope_append(mfma)");
         return NSA_OK;
     }
@@ -489,6 +505,37 @@ int launch_cmp_pool_bwd(const CmpPoolParams &P, const void *dKc, const void *dVc
     else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(cmp_pool_bwd_kernel<__bf16>, dim3((unsigned)nblk), dim3(64), 0, st, P, (const __bf16 *)dKc, (const __bf16 *)dVc, (__bf16 *)dKr, (__bf16 *)dVr, S, n_cmp);
     else hipLaunchKernelGGL(cmp_pool_bwd_kernel<_Float16>, dim3((unsigned)nblk), dim3(64), 0, st, P, (const _Float16 *)dKc, (const _Float16 *)dVc, (_Float16 *)dKr, (_Float16 *)dVr, S, n_cmp);
     NSA_LAUNCH_CHECK("cmp_pool_bwd");
+    return NSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ RMSNorm of a few rows
+// y = (x * rsqrt(mean(x^2) + eps)) * w, one wave per row, rounded where the eager chain rounds (llama_block_nsa.py:16-19)
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T *__restrict__ x, const T *__restrict__ w, T *__restrict__ y, int M, int dim,
+                                                           float eps) {
+    const int lane = lane_id();
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const T *xr = x + (int64_t)m * dim;
+    float acc = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float v = Elt<T>::to_f(xr[i]);
+        acc += rnd<T>(v * v);
+    }
+    float r = rnd<T>(wave_sum(acc) / (float)dim);
+    r = rnd<T>(r + eps);
+    r = rnd<T>(1.0f / sqrtf(r));
+    T *yr = y + (int64_t)m * dim;
+    for (int i = lane; i < dim; i += 64) yr[i] = Elt<T>::from_f(rnd<T>(Elt<T>::to_f(xr[i]) * r) * Elt<T>::to_f(w[i]));
+}
+
+int launch_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, hipStream_t st) {
+    if (M == 0) return NSA_OK;
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rmsnorm_rows_kernel<float>, grid, block, 0, st, (const float *)x, (const float *)w, (float *)y, M, dim, eps);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rmsnorm_rows_kernel<__bf16>, grid, block, 0, st, (const __bf16 *)x, (const __bf16 *)w, (__bf16 *)y, M, dim, eps);
+    else hipLaunchKernelGGL(rmsnorm_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16 *)x, (const _Float16 *)w, (_Float16 *)y, M, dim, eps);
+    NSA_LAUNCH_CHECK("rmsnorm_rows");
     return NSA_OK;
 }
 

@@ -42,6 +42,9 @@ struct DecodeFinishParams {
 int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st);
 int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st);
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
+// epi: 0 none, 1 silu, 2 + res[M,N]
+int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, hipStream_t st);
+int launch_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, hipStream_t st);
 int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st);
 int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st);
 int launch_rope_cache_append_bwd(const RopeAppendParams &P, int dtype, hipStream_t st);

@@ -29,12 +29,21 @@ static int check_kv(const nsa_kv_desc *kv, const char *who) {
 
 extern "C" {
 
-int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, void *stream) {
+int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epilogue, const void *residual, void *stream) {
     NSA_CHECK_ARG(dt_ok(dtype), "linear_small: unknown dtype %d", dtype);
     NSA_CHECK_ARG(M >= 0 && N >= 0 && K >= 1, "linear_small: bad sizes");
+    NSA_CHECK_ARG(epilogue >= 0 && epilogue <= 2 && (epilogue != 2 || residual), "linear_small: bad epilogue");
     if (M == 0 || N == 0) return NSA_OK;
     NSA_CHECK_ARG(A && W && out, "linear_small: null pointer");
-    return launch_linear_small(A, W, out, M, N, K, dtype, (hipStream_t)stream);
+    return launch_linear_small_epi(A, W, out, M, N, K, dtype, epilogue, residual, (hipStream_t)stream);
+}
+
+int nsa_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, void *stream) {
+    NSA_CHECK_ARG(dt_ok(dtype), "rmsnorm_rows: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(M >= 0 && dim >= 1, "rmsnorm_rows: bad sizes");
+    if (M == 0) return NSA_OK;
+    NSA_CHECK_ARG(x && w && y, "rmsnorm_rows: null pointer");
+    return launch_rmsnorm_rows(x, w, y, M, dim, eps, dtype, (hipStream_t)stream);
 }
 
 int nsa_rope_cache_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, void *Q_out, int S, int t0,
@@ -234,9 +243,9 @@ size_t nsa_layer_decode_step_workspace(const nsa_layer_desc *L, int B, int S_max
     return decode_ws(L, B, S_max).total;
 }
 
-int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
-                          const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
-                          void *workspace, size_t workspace_bytes, void *stream) {
+static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
+                                  const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
+                                  void *workspace, size_t workspace_bytes, void *stream, const void *residual) {
     if (int rc = check_layer(L, "layer_decode_step")) return rc;
     if (int rc = check_kv(kv, "layer_decode_step")) return rc;
     NSA_CHECK_ARG(x && y && L->W_qkv && L->W_out, "layer_decode_step: null pointer");
@@ -327,7 +336,62 @@ int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const 
     } else {
         if (int rc = nsa_gate_combine(L, Q, Ocmp, Osel, Owin, Omix, gates_out, (int64_t)B * G, stream)) return rc;
     }
-    return launch_linear_small(Omix, L->W_out, y, B, L->dim, NO, dt, st);
+    return launch_linear_small_epi(Omix, L->W_out, y, B, L->dim, NO, dt, residual ? 2 : 0, residual, st);
+}
+
+int nsa_layer_decode_step(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
+                          const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    return layer_decode_step_impl(L, kv, x, y, t, csc_ptr, csc_rows, csc_vals, S_sel, ranges_out, gates_out, workspace, workspace_bytes, stream,
+                                  nullptr);
+}
+
+// block workspace: xn | h | hn | u [B, mlp_hidden] | layer decode workspace
+struct BlockWs {
+    size_t xn, h, hn, u, layer, total, layer_bytes;
+};
+static BlockWs block_ws(const nsa_block_desc *Bk, int B, int S_max) {
+    BlockWs w;
+    const size_t e = esize(Bk->attn.dtype);
+    size_t o = 0;
+    w.xn = o; o += up256((size_t)B * Bk->attn.dim * e);
+    w.h = o; o += up256((size_t)B * Bk->attn.dim * e);
+    w.hn = o; o += up256((size_t)B * Bk->attn.dim * e);
+    w.u = o; o += up256((size_t)B * Bk->mlp_hidden * e);
+    w.layer_bytes = decode_ws(&Bk->attn, B, S_max).total;
+    w.layer = o; o += up256(w.layer_bytes);
+    w.total = o;
+    return w;
+}
+
+size_t nsa_block_decode_step_workspace(const nsa_block_desc *Bk, int B, int S_max) {
+    if (!Bk || !dt_ok(Bk->attn.dtype) || B < 1 || S_max < 1 || Bk->mlp_hidden < 1) return 0;
+    return block_ws(Bk, B, S_max).total;
+}
+
+int nsa_block_decode_step(const nsa_block_desc *Bk, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
+                          const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(Bk, "block_decode_step: null descriptor");
+    if (int rc = check_layer(&Bk->attn, "block_decode_step")) return rc;
+    if (int rc = check_kv(kv, "block_decode_step")) return rc;
+    NSA_CHECK_ARG(x && y && Bk->norm1_w && Bk->norm2_w && Bk->mlp_w1 && Bk->mlp_w2 && Bk->mlp_hidden >= 1, "block_decode_step: null pointer");
+    const int B = kv->B, dim = Bk->attn.dim, dt = Bk->attn.dtype;
+    const BlockWs W = block_ws(Bk, B, kv->S_max);
+    NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 256 == 0) && workspace_bytes >= W.total,
+                  "block_decode_step: workspace missing, misaligned or too small");
+    unsigned char *ws = (unsigned char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    void *xn = ws + W.xn, *h = ws + W.h, *hn = ws + W.hn, *u = ws + W.u;
+    const float eps = Bk->norm_eps > 0.f ? Bk->norm_eps : 1e-6f;
+    if (int rc = launch_rmsnorm_rows(x, Bk->norm1_w, xn, B, dim, eps, dt, st)) return rc;
+    // h = x + attn(norm1(x)): the residual rides in the output projection's epilogue
+    if (int rc = layer_decode_step_impl(&Bk->attn, kv, xn, h, t, csc_ptr, csc_rows, csc_vals, S_sel, ranges_out, gates_out, ws + W.layer,
+                                        W.layer_bytes, stream, x))
+        return rc;
+    if (int rc = launch_rmsnorm_rows(h, Bk->norm2_w, hn, B, dim, eps, dt, st)) return rc;
+    if (int rc = launch_linear_small_epi(hn, Bk->mlp_w1, u, B, Bk->mlp_hidden, dim, dt, 1, nullptr, st)) return rc;  // silu(fc1)
+    return launch_linear_small_epi(u, Bk->mlp_w2, y, B, dim, Bk->mlp_hidden, dt, 2, h, st);                         // fc2 + h
 }
 
 }  // extern "C"

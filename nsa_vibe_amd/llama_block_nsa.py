@@ -14,8 +14,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import ctypes
+
+from . import _lib
 from .kv_cache import NSA_KV
 from .nsa_attention import NSAAttention
+from .selection_scorer import _stream, workspace
 
 
 class RMSNorm(nn.Module):
@@ -58,10 +62,64 @@ class LlamaBlockNSA(nn.Module):
         block appends to that cache (prefill=True for the first S tokens, prefill=False for one decode token)."""
         if kv is None:
             kv = self.attn.new_kv(x.shape[0], x.shape[1], x.device, x.dtype)
+        if not prefill and x.shape[1] == 1 and self.attn._native_ok(x) and self.norm1.weight.dtype == x.dtype:
+            y = self._decode_native(x, kv)
+            return (y, kv) if return_kv else y
         out, kv = self.attn(self.norm1(x), kv, prefill=prefill)
         x = x + out
         x = x + self.mlp(self.norm2(x))
         return (x, kv) if return_kv else x
+
+
+    # ---- one native call per block and decode token (nsa_block_decode_step) ------------------------------------------
+    def _block_desc(self):
+        a = self.attn
+        ldesc, _ = a._layer_desc()
+        ps = [self.norm1.weight, self.norm2.weight, self.mlp.fc1.weight, self.mlp.fc2.weight]
+        key = (id(ldesc),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_bdesc_key", None) != key:
+            keep = [p.detach().contiguous() for p in ps]
+            d = _lib.NsaBlockDesc()
+            ctypes.memmove(ctypes.byref(d.attn), ctypes.byref(ldesc), ctypes.sizeof(ldesc))
+            d.norm1_w, d.norm2_w, d.mlp_w1, d.mlp_w2 = (k.data_ptr() for k in keep)
+            d.mlp_hidden, d.norm_eps = self.mlp.fc1.out_features, float(self.norm1.eps)
+            self._bdesc_key, self._bdesc, self._bdesc_keep = key, d, keep
+        return self._bdesc
+
+    def _decode_native(self, x: torch.Tensor, kv: NSA_KV) -> torch.Tensor:
+        a = self.attn
+        t, B, dev = kv.t, x.shape[0], x.device
+        if t + 1 > kv._K_sel.shape[2]:
+            raise RuntimeError(f"NSA_KV capacity exceeded: {t}+1 > S_max={kv.S_max}")
+        if kv.meta.S_sel == 0:
+            kv.ensure_meta(max(t + 1, a.l_sel))
+        elif t + 1 > kv.meta.S_sel * a.l_sel:
+            kv.ensure_meta(t + 1)
+        L = _lib.lib()
+        desc = self._block_desc()
+        ctx = getattr(kv, "_blk_ctx", None)
+        if ctx is None or ctx[0] is not desc:
+            kd = a._kv_desc(kv)
+            ws = workspace(dev, L.nsa_block_decode_step_workspace(ctypes.byref(desc), B, kd.S_max) + 256, "block_decode")
+            wptr = (ws.data_ptr() + 255) & ~255
+            ranges = torch.empty((B, a.n_kv_groups, a.n_sel, 2), dtype=torch.int32, device=dev)
+            gates = torch.empty((B, 1, a.n_kv_groups, 3), dtype=torch.float32, device=dev)
+            ctx = kv._blk_ctx = (desc, ctypes.byref(desc), ctypes.byref(kd), kd, ws, wptr, ws.numel() - (wptr - ws.data_ptr()), ranges, gates)
+        _, desc_ref, kd_ref, _, _, wptr, wsize, ranges, gates = ctx
+        cptr, crows, cvals = kv.meta.device_csc(dev)
+        xc = x.reshape(B, a.dim)
+        if not xc.is_contiguous():
+            xc = xc.contiguous()
+        y = torch.empty((B, 1, a.dim), dtype=x.dtype, device=dev)
+        rc = L.nsa_block_decode_step(desc_ref, kd_ref, xc.data_ptr(), y.data_ptr(), t, cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(),
+                                     int(kv.meta.S_sel), ranges.data_ptr(), gates.data_ptr(), wptr, wsize, _stream(dev))
+        _lib.check(rc, "nsa_block_decode_step")
+        S_raw = t + 1
+        num_cmp = 0 if S_raw < a.l else (S_raw - a.l) // a.d + 1
+        kv.t, kv.n_cmp = S_raw, num_cmp
+        kv.append_reads(num_cmp, S_raw)
+        a._last_ranges, a._last_gates = ranges, gates
+        return y
 
 
 class TinyLM(nn.Module):

@@ -220,7 +220,7 @@ def test_linear_small(dtype, M):
     A = torch.randn(M, K, device="cuda").to(dtype)
     W = (torch.randn(N, K, device="cuda") / 28.0).to(dtype)
     out = torch.empty(M, N, device="cuda", dtype=dtype)
-    _lib.check(_lib.lib().nsa_linear_small(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, _DT[dtype], _stream(A.device)), "linear")
+    _lib.check(_lib.lib().nsa_linear_small(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, _DT[dtype], 0, None, _stream(A.device)), "linear")
     ref = F.linear(A.float(), W.float())
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
@@ -412,3 +412,30 @@ def test_tiny_lm_prefill_decode_consistency():
         lm.prefill(tok[:, :S], caches)
         step = lm.decode(tok[:, S:], caches)
     assert (step[:, 0] - full[:, S]).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 8e-2)])
+def test_block_native_decode_matches_eager(dtype, tol, monkeypatch):
+    """LlamaBlockNSA decode: one native call per block (RMSNorm -> layer step with residual epilogue -> RMSNorm -> fc1+silu -> fc2+residual)
+    against the eager composition of the same modules"""
+    from nsa_vibe_amd.llama_block_nsa import LlamaBlockNSA
+
+    torch.manual_seed(4)
+    blk = LlamaBlockNSA(256, 8, 2, 64, 64, l=32, d=16, l_sel=64, n_sel=4, w=96).cuda().to(dtype).eval()
+    B, S, n_dec = 3, 200, 24
+    x = torch.randn(B, S + n_dec, 256, device="cuda", dtype=dtype)
+    outs = {}
+    for mode in ("native", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        kv = blk.attn.new_kv(B, S + n_dec, "cuda", dtype)
+        with torch.set_grad_enabled(mode == "eager"):
+            blk(x[:, :S], kv, prefill=True)
+            dec = [blk(x[:, t: t + 1], kv, prefill=False).detach() for t in range(S, S + n_dec)]
+        outs[mode] = torch.cat(dec, dim=1).float()
+    err = (outs["native"] - outs["eager"]).abs().amax(dim=-1)
+    assert torch.isfinite(outs["native"]).all()
+    if dtype == torch.float32:
+        assert err.max().item() <= tol
+    else:
+        assert err.median().item() <= tol and (err <= tol).float().mean().item() >= 0.9
