@@ -198,6 +198,36 @@ def layer_train_bench(nv, B, S, device, iters=5):
     return {"fwd_ms": tf, "bwd_ms": tb, "tok_per_s": B * S / ((tf + tb) * 1e-3)}
 
 
+def model_bench(B, S, device, steps=24):
+    """m7c_125m TinyLM (12 x LlamaBlockNSA, GPT-2 vocabulary, random weights): prefill ms and decode tokens/s of the whole model"""
+    from nsa_vibe_amd.llama_block_nsa import TinyLM
+
+    torch.manual_seed(0)
+    lm = TinyLM(50257, 768, 12, 12, G, D, D, L_CMP, D_CMP, L_SEL, N_SEL, 512, selector="batched").to(device).to(torch.bfloat16).eval()
+    tok = torch.randint(0, 50257, (B, S), device=device)
+    with torch.no_grad():
+        best = 1e9
+        for _ in range(3):
+            caches = lm.new_caches(B, S + steps + 16, device, torch.bfloat16)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            logits = lm.prefill(tok, caches)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        nxt = logits.argmax(-1)
+        for _ in range(8):
+            nxt = lm.decode(nxt, caches).argmax(-1)
+        dt = 1e9
+        for _ in range(max(1, steps // 8)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                nxt = lm.decode(nxt, caches).argmax(-1)
+            torch.cuda.synchronize()
+            dt = min(dt, (time.perf_counter() - t0) / 8)
+    return {"prefill_ms": best * 1e3, "decode_ms_per_token": dt * 1e3, "decode_tok_per_s": B / dt}
+
+
 def cpu_baseline(S, B, seed=3, min_seconds=10.0):
     """The oracle (CPU restatement of the reference path, fp32) on the same workload, repeated over the batch
     until ~10 s of host time have been spent (bounded sample)."""
@@ -413,6 +443,9 @@ def main():
                 for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
                     extra[f"layer_S{S2}_B{B2}"] = layer_bench(nv, B2, S2, device)
                 extra[f"layer_train_S{S}_B{B}"] = layer_train_bench(nv, B, S, device)
+                # the whole m7c_125m model (BASELINE configs 2-4 name it): attention layers native, norms / MLP / head PyTorch-ROCm
+                for S2, B2 in ((4096, 1), (16384, 1), (4096, 32)):
+                    extra[f"model_m7c_125m_S{S2}_B{B2}"] = model_bench(B2, S2, device)
             except Exception as e:  # noqa: BLE001 -- extras must not void the headline number
                 extra["error"] = repr(e)
             out["extra"] = extra
