@@ -65,11 +65,35 @@ class LlamaBlockNSA(nn.Module):
         if not prefill and x.shape[1] == 1 and self.attn._native_ok(x) and self.norm1.weight.dtype == x.dtype:
             y = self._decode_native(x, kv)
             return (y, kv) if return_kv else y
+        if prefill and kv.t == 0 and self.attn._native_ok(x) and self.norm1.weight.dtype == x.dtype:
+            y = self._prefill_native(x, kv)
+            return (y, kv) if return_kv else y
         out, kv = self.attn(self.norm1(x), kv, prefill=prefill)
         x = x + out
         x = x + self.mlp(self.norm2(x))
         return (x, kv) if return_kv else x
 
+
+    # ---- inference prefill: native RMSNorm + native layer core, residuals folded into the GEMMs (addmm) -----------------
+    def _rmsnorm_native(self, x2d: torch.Tensor, norm: RMSNorm) -> torch.Tensor:
+        from .selection_scorer import _DT
+
+        y = torch.empty_like(x2d)
+        rc = _lib.lib().nsa_rmsnorm_rows(x2d.data_ptr(), norm.weight.data_ptr(), y.data_ptr(), x2d.shape[0], x2d.shape[1], float(norm.eps),
+                                         _DT[x2d.dtype], _stream(x2d.device))
+        _lib.check(rc, "nsa_rmsnorm_rows")
+        return y
+
+    def _prefill_native(self, x: torch.Tensor, kv: NSA_KV) -> torch.Tensor:
+        B, S, dim = x.shape
+        x2 = x.reshape(B * S, dim)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        xn = self._rmsnorm_native(x2, self.norm1).view(B, S, dim)
+        O, _ = self.attn._prefill_native(xn, kv, mix_only=True)                  # [B,S,H*Dv], before the output projection
+        h = torch.addmm(x2, O.view(B * S, -1), self.attn.out.weight.t())          # x + out(O)
+        u = F.silu(F.linear(self._rmsnorm_native(h, self.norm2), self.mlp.fc1.weight))
+        return torch.addmm(h, u, self.mlp.fc2.weight.t()).view(B, S, dim)         # h + fc2(u)
 
     # ---- one native call per block and decode token (nsa_block_decode_step) ------------------------------------------
     def _block_desc(self):

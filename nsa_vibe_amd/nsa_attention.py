@@ -360,7 +360,7 @@ class NSAAttention(nn.Module):
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S], kv._V_win[:, :, :S], self.w, scale=scale)
         return self._combine(Q, O_cmp, O_sel, O_win), kv
 
-    def _prefill_native(self, x: torch.Tensor, kv: NSA_KV):
+    def _prefill_native(self, x: torch.Tensor, kv: NSA_KV, mix_only: bool = False):
         """inference prefill: fused projection GEMM -> ONE native call for everything up to the output projection
         (nsa_layer_prefill: RoPE + cache append, pooling, scores, top-n + selection attention, sliding / compressed branches,
         gates + combine) -> output GEMM"""
@@ -392,7 +392,7 @@ class NSAAttention(nn.Module):
         kv.t = S
         kv.n_cmp = 0 if S < self.l else (S - self.l) // self.d + 1
         self._last_ranges, self._last_gates = ranges, gates
-        return self.out(O), kv
+        return O if mix_only else self.out(O), kv
 
     def _prefill_train_native(self, x: torch.Tensor, kv: NSA_KV):
         """training forward: one fused projection GEMM, then every stage is a differentiable native op (the attention branches

@@ -430,9 +430,9 @@ def test_block_native_decode_matches_eager(dtype, tol, monkeypatch):
             monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
         kv = blk.attn.new_kv(B, S + n_dec, "cuda", dtype)
         with torch.set_grad_enabled(mode == "eager"):
-            blk(x[:, :S], kv, prefill=True)
+            pre = blk(x[:, :S], kv, prefill=True).detach()
             dec = [blk(x[:, t: t + 1], kv, prefill=False).detach() for t in range(S, S + n_dec)]
-        outs[mode] = torch.cat(dec, dim=1).float()
+        outs[mode] = torch.cat([pre] + dec, dim=1).float()  # prefill rows (native: RMSNorm kernel + addmm residuals) and decode rows
     err = (outs["native"] - outs["eager"]).abs().amax(dim=-1)
     assert torch.isfinite(outs["native"]).all()
     if dtype == torch.float32:
