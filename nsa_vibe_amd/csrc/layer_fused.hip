@@ -56,6 +56,22 @@ __device__ __forceinline__ void load8(const T *p, int nvalid, bool vec, float (&
 }
 
 // one wave per output column n (W row n stays in registers), rows of A in chunks of 8
+// RMSNorm folded into a small-M projection: rsqrt(mean(x^2) + eps) of one row, computed by the whole wave with the rounding points
+// of the eager chain (llama_block_nsa.py:16-19); the caller then feeds rnd(rnd(x * r) * g) into its dot products
+template <typename T>
+__device__ __forceinline__ float row_rms(const T *xr, int K, bool vec, float eps) {
+    float acc = 0.f;
+    for (int k = lane_id() * 8; k < K; k += 512) {
+        float v[8];
+        load8<T>(xr + k, K - k, vec, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += rnd<T>(v[j] * v[j]);
+    }
+    float r = rnd<T>(wave_sum(acc) / (float)K);
+    r = rnd<T>(r + eps);
+    return rnd<T>(1.0f / sqrtf(r));
+}
+
 template <typename T>
 __device__ __forceinline__ float linear_epilogue(float acc, int epi, const T *res, int64_t idx) {
     float v = rnd<T>(acc);  // the GEMM result in the activation dtype, then the fused elementwise op rounds again like the eager chain
@@ -66,7 +82,8 @@ __device__ __forceinline__ float linear_epilogue(float acc, int epi, const T *re
 
 template <typename T>
 __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M,
-                                                           int N, int K, int epi, const T *__restrict__ res) {
+                                                           int N, int K, int epi, const T *__restrict__ res, const T *__restrict__ norm_w,
+                                                           float norm_eps) {
     const int lane = lane_id();
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -75,11 +92,19 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__
     for (int m0 = 0; m0 < M; m0 += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int mm = min(8, M - m0);
+        float rms[8];
+        if (norm_w)
+            for (int r = 0; r < mm; ++r) rms[r] = row_rms<T>(A + (int64_t)(m0 + r) * K, K, vec, norm_eps);
         for (int k = lane * 8; k < K; k += 512) {
-            float wv[8], av[8];
+            float wv[8], av[8], gv[8];
             load8<T>(w + k, K - k, vec, wv);
+            if (norm_w) load8<T>(norm_w + k, K - k, vec && ((uintptr_t)norm_w % 16 == 0), gv);
             for (int r = 0; r < mm; ++r) {
                 load8<T>(A + (int64_t)(m0 + r) * K + k, K - k, vec, av);
+                if (norm_w) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = rnd<T>(rnd<T>(av[j] * rms[r]) * gv[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], av[j], acc[r]);
             }
@@ -92,17 +117,18 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__
 }
 
 template <typename T>
-static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, int epi, const void *res, hipStream_t st) {
+static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, int epi, const void *res, const void *norm_w, float eps,
+                          hipStream_t st) {
     hipLaunchKernelGGL(linear_small_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K, epi,
-                       (const T *)res);
+                       (const T *)res, (const T *)norm_w, eps);
     NSA_LAUNCH_CHECK("linear_small");
     return NSA_OK;
 }
 static int launch_linear_small_valu(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res,
-                                    hipStream_t st) {
-    if (dtype == NSA_DT_F32) return linear_small_t<float>(A, W, out, M, N, K, epi, res, st);
-    if (dtype == NSA_DT_BF16) return linear_small_t<__bf16>(A, W, out, M, N, K, epi, res, st);
-    return linear_small_t<_Float16>(A, W, out, M, N, K, epi, res, st);
+                                    const void *norm_w, float eps, hipStream_t st) {
+    if (dtype == NSA_DT_F32) return linear_small_t<float>(A, W, out, M, N, K, epi, res, norm_w, eps, st);
+    if (dtype == NSA_DT_BF16) return linear_small_t<__bf16>(A, W, out, M, N, K, epi, res, norm_w, eps, st);
+    return linear_small_t<_Float16>(A, W, out, M, N, K, epi, res, norm_w, eps, st);
 }
 
 // ------------------------------------------------------------------------------------------ RoPE + cache append
@@ -278,7 +304,8 @@ __device__ __forceinline__ void rope_store_pair(const RopeAppendParams &P, int b
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W, int K) {
+__global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W, int K,
+                                                              const T *__restrict__ norm_w, float norm_eps) {
     const int lane = lane_id();
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -289,12 +316,20 @@ __global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P
     for (int m0 = 0; m0 < M; m0 += 8) {
         float a0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int mm = min(8, M - m0);
+        float rms[8];
+        if (norm_w)
+            for (int r = 0; r < mm; ++r) rms[r] = row_rms<T>(X + (int64_t)(m0 + r) * K, K, vec, norm_eps);
         for (int k = lane * 8; k < K; k += 512) {
-            float u0[8], u1[8], xv[8];
+            float u0[8], u1[8], xv[8], gv[8];
             load8<T>(w0 + k, K - k, vec, u0);
             load8<T>(w1 + k, K - k, vec, u1);
+            if (norm_w) load8<T>(norm_w + k, K - k, vec && ((uintptr_t)norm_w % 16 == 0), gv);
             for (int r = 0; r < mm; ++r) {
                 load8<T>(X + (int64_t)(m0 + r) * K + k, K - k, vec, xv);
+                if (norm_w) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = rnd<T>(rnd<T>(xv[j] * rms[r]) * gv[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     a0[r] = fmaf(u0[j], xv[j], a0[r]);
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, co
 }
 
 static bool linear_mfma_ok(int dtype, int M, int N, int K, const void *X, const void *W) {
-    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 9 && N % 16 == 0 && K % 32 == 0 &&
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 3 && N % 16 == 0 && K % 32 == 0 &&
            (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
 }
 
@@ -390,15 +425,28 @@ int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int 
         NSA_LAUNCH_CHECK("linear_small(mfma)");
         return NSA_OK;
     }
-    return launch_linear_small_valu(A, W, out, M, N, K, dtype, epi, res, st);
+    return launch_linear_small_valu(A, W, out, M, N, K, dtype, epi, res, nullptr, 0.f, st);
+}
+// RMSNorm(x) folded into the projection (rows <= 8: the VALU kernel); returns NSA_ERR_INVALID without side effects when not applicable
+bool linear_small_can_fold_norm(int dtype, int M, int N, int K, const void *A, const void *W) { return !linear_mfma_ok(dtype, M, N, K, A, W); }
+int launch_linear_small_norm(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, const void *norm_w,
+                             float eps, hipStream_t st) {
+    return launch_linear_small_valu(A, W, out, M, N, K, dtype, epi, res, norm_w, eps, st);
 }
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st) {
     return launch_linear_small_epi(A, W, out, M, N, K, dtype, 0, nullptr, st);
 }
 
-int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st) {
+// norm_w != nullptr: RMSNorm(X) is folded into the projection (only taken by the VALU form, i.e. when qkv_can_fold_norm())
+bool qkv_can_fold_norm(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype) {
+    const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
+    return !linear_mfma_ok(dtype, P.B, NT, K, X, W);
+}
+int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st, const void *norm_w,
+                           float norm_eps) {
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
     if (linear_mfma_ok(dtype, P.B, NT, K, X, W)) {
+        NSA_CHECK_ARG(norm_w == nullptr, "qkv_rope_append: the MFMA form takes normalised input");
         const dim3 g2((unsigned)(NT / 16), (unsigned)((P.B + 63) / 64));
         if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K, 0, (const __bf16 *)nullptr);
         else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K, 0, (const _Float16 *)nullptr);
@@ -406,13 +454,12 @@ int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void 
         return NSA_OK;
     }
     const dim3 grid((unsigned)((NT / 2 + 3) / 4)), block(256);
-    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(qkv_rope_append_kernel<float>, grid, block, 0, st, P, (const float *)X, (const float *)W, K);
-    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(qkv_rope_append_kernel<__bf16>, grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K);
-    else hipLaunchKernelGGL(qkv_rope_append_kernel<_Float16>, grid, block, 0, st, P, (const _Float16 *)X, (const _Float16 *)W, K);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(qkv_rope_append_kernel<float>, grid, block, 0, st, P, (const float *)X, (const float *)W, K, (const float *)norm_w, norm_eps);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(qkv_rope_append_kernel<__bf16>, grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K, (const __bf16 *)norm_w, norm_eps);
+    else hipLaunchKernelGGL(qkv_rope_append_kernel<_Float16>, grid, block, 0, st, P, (const _Float16 *)X, (const _Float16 *)W, K, (const _Float16 *)norm_w, norm_eps);
     NSA_LAUNCH_CHECK("qkv_rope_append");
     return NSA_OK;
 }
-
 
 // ------------------------------------------------------------------------------------------ compressed-token emission
 // one 64-thread block per (b, g, j): K_cmp[j] = mean_i rope(K_raw[j d + i], pos = j d + i), V_cmp[j] = mean_i V_raw[j d + i]

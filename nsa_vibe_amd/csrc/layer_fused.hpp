@@ -39,7 +39,12 @@ struct DecodeFinishParams {
     int h, Dk, Dv, Hd;
     float tau;
 };
-int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st);
+bool qkv_can_fold_norm(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype);
+int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void *W, int K, int dtype, hipStream_t st, const void *norm_w = nullptr,
+                           float norm_eps = 0.f);
+bool linear_small_can_fold_norm(int dtype, int M, int N, int K, const void *A, const void *W);
+int launch_linear_small_norm(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, const void *norm_w,
+                             float eps, hipStream_t st);
 int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st);
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
 // epi: 0 none, 1 silu, 2 + res[M,N]

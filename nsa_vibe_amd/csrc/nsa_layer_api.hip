@@ -245,7 +245,8 @@ size_t nsa_layer_decode_step_workspace(const nsa_layer_desc *L, int B, int S_max
 
 static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *x, void *y, int t, const int32_t *csc_ptr,
                                   const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
-                                  void *workspace, size_t workspace_bytes, void *stream, const void *residual) {
+                                  void *workspace, size_t workspace_bytes, void *stream, const void *residual, const void *norm_w = nullptr,
+                                  float norm_eps = 0.f) {
     if (int rc = check_layer(L, "layer_decode_step")) return rc;
     if (int rc = check_kv(kv, "layer_decode_step")) return rc;
     NSA_CHECK_ARG(x && y && L->W_qkv && L->W_out, "layer_decode_step: null pointer");
@@ -271,7 +272,7 @@ static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv
     RP.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
     RP.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
     // 1+2. fused QKV projection with RoPE + cache append at position t in its epilogue
-    if (int rc = launch_qkv_rope_append(RP, x, L->W_qkv, L->dim, dt, st)) return rc;
+    if (int rc = launch_qkv_rope_append(RP, x, L->W_qkv, L->dim, dt, st, norm_w, norm_eps)) return rc;
     // 3. emit a compressed token when a window completes (nsa_attention.py:588-604)
     const int S_raw = t + 1;
     const int n_cmp = S_raw < L->l ? 0 : (S_raw - L->l) / L->d + 1;
@@ -384,14 +385,23 @@ int nsa_block_decode_step(const nsa_block_desc *Bk, const nsa_kv_desc *kv, const
     hipStream_t st = (hipStream_t)stream;
     void *xn = ws + W.xn, *h = ws + W.h, *hn = ws + W.hn, *u = ws + W.u;
     const float eps = Bk->norm_eps > 0.f ? Bk->norm_eps : 1e-6f;
-    if (int rc = launch_rmsnorm_rows(x, Bk->norm1_w, xn, B, dim, eps, dt, st)) return rc;
+    // small batches: both RMSNorms are folded into the projections that consume them (two launches fewer per block)
+    RopeAppendParams probe{};
+    probe.B = B; probe.G = Bk->attn.G; probe.h = Bk->attn.h; probe.Dk = Bk->attn.Dk; probe.Dv = Bk->attn.Dv;
+    const bool fold1 = qkv_can_fold_norm(probe, x, Bk->attn.W_qkv, dim, dt);
+    if (!fold1)
+        if (int rc = launch_rmsnorm_rows(x, Bk->norm1_w, xn, B, dim, eps, dt, st)) return rc;
     // h = x + attn(norm1(x)): the residual rides in the output projection's epilogue
-    if (int rc = layer_decode_step_impl(&Bk->attn, kv, xn, h, t, csc_ptr, csc_rows, csc_vals, S_sel, ranges_out, gates_out, ws + W.layer,
-                                        W.layer_bytes, stream, x))
+    if (int rc = layer_decode_step_impl(&Bk->attn, kv, fold1 ? x : xn, h, t, csc_ptr, csc_rows, csc_vals, S_sel, ranges_out, gates_out,
+                                        ws + W.layer, W.layer_bytes, stream, x, fold1 ? Bk->norm1_w : nullptr, eps))
         return rc;
-    if (int rc = launch_rmsnorm_rows(h, Bk->norm2_w, hn, B, dim, eps, dt, st)) return rc;
-    if (int rc = launch_linear_small_epi(hn, Bk->mlp_w1, u, B, Bk->mlp_hidden, dim, dt, 1, nullptr, st)) return rc;  // silu(fc1)
-    return launch_linear_small_epi(u, Bk->mlp_w2, y, B, dim, Bk->mlp_hidden, dt, 2, h, st);                         // fc2 + h
+    if (linear_small_can_fold_norm(dt, B, Bk->mlp_hidden, dim, h, Bk->mlp_w1)) {
+        if (int rc = launch_linear_small_norm(h, Bk->mlp_w1, u, B, Bk->mlp_hidden, dim, dt, 1, nullptr, Bk->norm2_w, eps, st)) return rc;
+    } else {
+        if (int rc = launch_rmsnorm_rows(h, Bk->norm2_w, hn, B, dim, eps, dt, st)) return rc;
+        if (int rc = launch_linear_small_epi(hn, Bk->mlp_w1, u, B, Bk->mlp_hidden, dim, dt, 1, nullptr, st)) return rc;  // silu(fc1)
+    }
+    return launch_linear_small_epi(u, Bk->mlp_w2, y, B, dim, Bk->mlp_hidden, dt, 2, h, st);  // fc2 + h
 }
 
 }  // extern "C"
