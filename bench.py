@@ -216,13 +216,13 @@ def model_bench(B, S, device, steps=24):
             best = min(best, time.perf_counter() - t0)
         nxt = logits.argmax(-1)
         for _ in range(8):
-            nxt = lm.decode(nxt, caches).argmax(-1)
+            nxt = lm.decode(nxt, caches, return_next=True)[1]
         dt = 1e9
         for _ in range(max(1, steps // 8)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(8):
-                nxt = lm.decode(nxt, caches).argmax(-1)
+                nxt = lm.decode(nxt, caches, return_next=True)[1]
             torch.cuda.synchronize()
             dt = min(dt, (time.perf_counter() - t0) / 8)
     return {"prefill_ms": best * 1e3, "decode_ms_per_token": dt * 1e3, "decode_tok_per_s": B / dt}

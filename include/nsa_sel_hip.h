@@ -196,6 +196,15 @@ NSA_API int nsa_block_decode_step(const nsa_block_desc *Bk, const nsa_kv_desc *k
                           const int32_t *csc_rows, const float *csc_vals, int S_sel, int32_t *ranges_out, float *gates_out,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* One decode step of a whole TinyLM-style stack (scripts/train_showcase.py:30-110) in one call: embedding rows of tokens[B] ->
+ * n_blocks x nsa_block_decode_step (all at position t, each with its own cache) -> final RMSNorm -> LM head -> logits [B,vocab]
+ * (activation dtype) and, when next_tokens != NULL, their argmax.  blocks / kvs are host arrays of n_blocks descriptors. */
+NSA_API size_t nsa_model_decode_step_workspace(const nsa_block_desc *blocks, int n_blocks, int B, int S_max);
+NSA_API int nsa_model_decode_step(const nsa_block_desc *blocks, const nsa_kv_desc *kvs, int n_blocks, const int32_t *tokens,
+                          const void *embed, const void *norm_f_w, const void *lm_head, int vocab, void *logits,
+                          int32_t *next_tokens, int t, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
+                          int S_sel, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Prefill of the whole layer between the two big GEMMs, in one call (nsa_attention.py:978-1448 / 1521-1723): proj [B,S,NQ+3GDk+3GDv]
  * (= x @ W_qkv^T) -> RoPE + append of the S tokens into the EMPTY caches -> compressed-token pooling -> selection scores ->
  * top-n + selection attention -> sliding and compressed branches -> gates + combine -> O_mix [B,S,G*h*Dv] (input of the output

@@ -116,11 +116,54 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const T *__restrict__
     }
 }
 
+// GEMV form for 1-2 rows and many columns (LM head): one wave = 4 output columns, so 4 weight rows are in flight per wave and the
+// weight matrix streams at memory speed; x (normalised on the fly when norm_w is given) is read once per wave
+template <typename T>
+__global__ __launch_bounds__(256) void linear_gemv4_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M, int N,
+                                                           int K, int epi, const T *__restrict__ res, const T *__restrict__ norm_w,
+                                                           float norm_eps) {
+    const int lane = lane_id();
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (n0 >= N) return;
+    const bool vec = (K % 8 == 0) && (((uintptr_t)A | (uintptr_t)W) % 16 == 0);
+    float rms[2] = {1.f, 1.f};
+    if (norm_w)
+        for (int r = 0; r < M; ++r) rms[r] = row_rms<T>(A + (int64_t)r * K, K, vec, norm_eps);
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int k = lane * 8; k < K; k += 512) {
+        float wv[4][8], av[2][8], gv[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) load8<T>(W + (int64_t)min(n0 + c, N - 1) * K + k, K - k, vec, wv[c]);
+        if (norm_w) load8<T>(norm_w + k, K - k, vec && ((uintptr_t)norm_w % 16 == 0), gv);
+        for (int r = 0; r < M; ++r) {
+            load8<T>(A + (int64_t)r * K + k, K - k, vec, av[r]);
+            if (norm_w) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[r][j] = rnd<T>(rnd<T>(av[r][j] * rms[r]) * gv[j]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c][r] = fmaf(wv[c][j], av[r][j], acc[c][r]);
+        }
+    }
+    for (int r = 0; r < M; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float sum = wave_sum(acc[c][r]);
+            if (lane == 0 && n0 + c < N) out[(int64_t)r * N + n0 + c] = Elt<T>::from_f(linear_epilogue<T>(sum, epi, res, (int64_t)r * N + n0 + c));
+        }
+}
+
 template <typename T>
 static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, int epi, const void *res, const void *norm_w, float eps,
                           hipStream_t st) {
-    hipLaunchKernelGGL(linear_small_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K, epi,
-                       (const T *)res, (const T *)norm_w, eps);
+    if (M <= 2 && N >= 4096)
+        hipLaunchKernelGGL(linear_gemv4_kernel<T>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K,
+                           epi, (const T *)res, (const T *)norm_w, eps);
+    else
+        hipLaunchKernelGGL(linear_small_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K, epi,
+                           (const T *)res, (const T *)norm_w, eps);
     NSA_LAUNCH_CHECK("linear_small");
     return NSA_OK;
 }
@@ -366,7 +409,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, co
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const T *wrow = W + (int64_t)(n0 + rho) * K + 8 * q;
+    const T *wrow = W + (int64_t)min(n0 + rho, N - 1) * K + 8 * q;  // the last column tile may be partial: clamp, store guarded
     for (int sb = s0; sb < s1; sb += 6) {  // 6 k-steps (30 loads) in flight per round
         x8 wf[6], xf[6][4];
 #pragma unroll
@@ -401,10 +444,12 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, co
     if (m >= M) return;
     if (ROPE) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) rope_store_pair<T>(P, m, 0, n0 + 4 * nq + 2 * p, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
+        for (int p = 0; p < 2; ++p)
+            if (n0 + 4 * nq + 2 * p < N) rope_store_pair<T>(P, m, 0, n0 + 4 * nq + 2 * p, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (n0 + 4 * nq + r >= N) break;
             const int64_t idx = (int64_t)m * N + n0 + 4 * nq + r;
             out[idx] = Elt<T>::from_f(linear_epilogue<T>(v[r], epi, res, idx));
         }
@@ -412,14 +457,14 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, co
 }
 
 static bool linear_mfma_ok(int dtype, int M, int N, int K, const void *X, const void *W) {
-    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 3 && N % 16 == 0 && K % 32 == 0 &&
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 3 && K % 32 == 0 &&
            (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
 }
 
 int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, hipStream_t st) {
     if (linear_mfma_ok(dtype, M, N, K, A, W)) {
         RopeAppendParams P{};
-        const dim3 g2((unsigned)(N / 16), (unsigned)((M + 63) / 64));
+        const dim3 g2((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
         if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res);
         else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res);
         NSA_LAUNCH_CHECK("linear_small(mfma)");
@@ -447,7 +492,7 @@ int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void 
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
     if (linear_mfma_ok(dtype, P.B, NT, K, X, W)) {
         NSA_CHECK_ARG(norm_w == nullptr, "qkv_rope_append: the MFMA form takes normalised input");
-        const dim3 g2((unsigned)(NT / 16), (unsigned)((P.B + 63) / 64));
+        const dim3 g2((unsigned)((NT + 15) / 16), (unsigned)((P.B + 63) / 64));
         if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K, 0, (const __bf16 *)nullptr);
         else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K, 0, (const _Float16 *)nullptr);
         NSA_LAUNCH_CHECK("qkv_rope_append(mfma)");
@@ -859,6 +904,99 @@ int launch_gate_combine(const GateCombineParams &P, int dtype, hipStream_t st) {
     else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(gate_combine_kernel<__bf16>, grid, block, 0, st, P);
     else hipLaunchKernelGGL(gate_combine_kernel<_Float16>, grid, block, 0, st, P);
     NSA_LAUNCH_CHECK("gate_combine");
+    return NSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ model-level helpers (decode)
+// x[b, :] = embed[tokens[b], :]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int32_t *__restrict__ tokens, const T *__restrict__ embed, T *__restrict__ x, int B,
+                                                         int dim, int vocab) {
+    const int b = blockIdx.x;
+    const int tok = min(max(tokens[b], 0), vocab - 1);
+    for (int i = threadIdx.x; i < dim; i += 256) x[(int64_t)b * dim + i] = embed[(int64_t)tok * dim + i];
+}
+int launch_embed_rows(const int32_t *tokens, const void *embed, void *x, int B, int dim, int vocab, int dtype, hipStream_t st) {
+    if (B == 0) return NSA_OK;
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(embed_rows_kernel<float>, dim3(B), dim3(256), 0, st, tokens, (const float *)embed, (float *)x, B, dim, vocab);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(embed_rows_kernel<__bf16>, dim3(B), dim3(256), 0, st, tokens, (const __bf16 *)embed, (__bf16 *)x, B, dim, vocab);
+    else hipLaunchKernelGGL(embed_rows_kernel<_Float16>, dim3(B), dim3(256), 0, st, tokens, (const _Float16 *)embed, (_Float16 *)x, B, dim, vocab);
+    NSA_LAUNCH_CHECK("embed_rows");
+    return NSA_OK;
+}
+
+// next[b] = argmax_v logits[b, v] (first maximum wins).  Stage 1: grid (chunks, B), one workgroup per 4096-value chunk -> (max, index)
+// partials; stage 2: one wave per row over the partials.
+constexpr int ARGMAX_CHUNK = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_part_kernel(const T *__restrict__ logits, float *__restrict__ pv, int32_t *__restrict__ pi, int vocab) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.y, lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const T *row = logits + (int64_t)b * vocab;
+    const int v0 = blockIdx.x * ARGMAX_CHUNK, v1 = min(vocab, v0 + ARGMAX_CHUNK);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+        const float x = Elt<T>::to_f(row[v]);
+        if (x > best) {
+            best = x;
+            bi = v;
+        }
+    }
+    const float wm = wave_max(best);
+    int cand = best == wm ? bi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) {
+        sv[wave] = wm;
+        si[wave] = cand;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = sv[0];
+        int i = si[0];
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > m || (sv[w] == m && si[w] < i)) {
+                m = sv[w];
+                i = si[w];
+            }
+        pv[(int64_t)b * gridDim.x + blockIdx.x] = m;
+        pi[(int64_t)b * gridDim.x + blockIdx.x] = i;
+    }
+}
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float *__restrict__ pv, const int32_t *__restrict__ pi, int32_t *__restrict__ next,
+                                                         int nchunk) {
+    const int b = blockIdx.x, lane = lane_id();
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < nchunk; c += 64) {
+        const float x = pv[(int64_t)b * nchunk + c];
+        const int i = pi[(int64_t)b * nchunk + c];
+        if (x > best || (x == best && i < bi)) {
+            best = x;
+            bi = i;
+        }
+    }
+    const float wm = wave_max(best);
+    int cand = best == wm ? bi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) next[b] = cand == 0x7fffffff ? 0 : cand;
+}
+size_t argmax_rows_workspace(int B, int vocab) { return (size_t)B * ((vocab + ARGMAX_CHUNK - 1) / ARGMAX_CHUNK) * 8; }
+int launch_argmax_rows(const void *logits, int32_t *next, int B, int vocab, int dtype, void *ws, hipStream_t st) {
+    if (B == 0) return NSA_OK;
+    const int nchunk = (vocab + ARGMAX_CHUNK - 1) / ARGMAX_CHUNK;
+    float *pv = (float *)ws;
+    int32_t *pi = (int32_t *)(pv + (size_t)B * nchunk);
+    const dim3 grid((unsigned)nchunk, (unsigned)B);
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(argmax_part_kernel<float>, grid, dim3(256), 0, st, (const float *)logits, pv, pi, vocab);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(argmax_part_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)logits, pv, pi, vocab);
+    else hipLaunchKernelGGL(argmax_part_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16 *)logits, pv, pi, vocab);
+    NSA_LAUNCH_CHECK("argmax_part");
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, (const float *)pv, (const int32_t *)pi, next, nchunk);
+    NSA_LAUNCH_CHECK("argmax_final");
     return NSA_OK;
 }
 

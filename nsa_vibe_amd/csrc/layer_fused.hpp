@@ -49,6 +49,9 @@ int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st)
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
 // epi: 0 none, 1 silu, 2 + res[M,N]
 int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, hipStream_t st);
+int launch_embed_rows(const int32_t *tokens, const void *embed, void *x, int B, int dim, int vocab, int dtype, hipStream_t st);
+size_t argmax_rows_workspace(int B, int vocab);
+int launch_argmax_rows(const void *logits, int32_t *next, int B, int vocab, int dtype, void *ws, hipStream_t st);
 int launch_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, hipStream_t st);
 int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st);
 int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st);

@@ -404,4 +404,57 @@ int nsa_block_decode_step(const nsa_block_desc *Bk, const nsa_kv_desc *kv, const
     return launch_linear_small_epi(u, Bk->mlp_w2, y, B, dim, Bk->mlp_hidden, dt, 2, h, st);  // fc2 + h
 }
 
+// model workspace: x ping | x pong | block workspace
+size_t nsa_model_decode_step_workspace(const nsa_block_desc *blocks, int n_blocks, int B, int S_max) {
+    if (!blocks || n_blocks < 1 || B < 1 || S_max < 1) return 0;
+    const size_t xb = up256((size_t)B * blocks[0].attn.dim * esize(blocks[0].attn.dtype));
+    size_t bw = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        const size_t w = nsa_block_decode_step_workspace(&blocks[i], B, S_max);
+        if (w == 0) return 0;
+        if (w > bw) bw = w;
+    }
+    return 2 * xb + up256(bw) + up256((size_t)B * 64 * 8);  // + argmax partials (up to 64 chunks of 4096 logits)
+}
+
+int nsa_model_decode_step(const nsa_block_desc *blocks, const nsa_kv_desc *kvs, int n_blocks, const int32_t *tokens, const void *embed,
+                          const void *norm_f_w, const void *lm_head, int vocab, void *logits, int32_t *next_tokens, int t,
+                          const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(blocks && kvs && n_blocks >= 1 && tokens && embed && norm_f_w && lm_head && logits && vocab >= 1, "model_decode_step: null pointer");
+    const int B = kvs[0].B, dim = blocks[0].attn.dim, dt = blocks[0].attn.dtype;
+    for (int i = 0; i < n_blocks; ++i)
+        NSA_CHECK_ARG(kvs[i].B == B && blocks[i].attn.dim == dim && blocks[i].attn.dtype == dt && kvs[i].S_max == kvs[0].S_max,
+                      "model_decode_step: blocks / caches disagree on batch, width, dtype or capacity");
+    const size_t need = nsa_model_decode_step_workspace(blocks, n_blocks, B, kvs[0].S_max);
+    NSA_CHECK_ARG(need > 0 && workspace && ((uintptr_t)workspace % 256 == 0) && workspace_bytes >= need,
+                  "model_decode_step: workspace missing, misaligned or too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t xb = up256((size_t)B * dim * esize(dt));
+    unsigned char *ws = (unsigned char *)workspace;
+    void *xa = ws, *xc = ws + xb;
+    unsigned char *bws = ws + 2 * xb;
+    if (int rc = launch_embed_rows(tokens, embed, xa, B, dim, vocab, dt, st)) return rc;
+    for (int i = 0; i < n_blocks; ++i) {
+        if (int rc = nsa_block_decode_step(&blocks[i], &kvs[i], xa, xc, t, csc_ptr, csc_rows, csc_vals, S_sel, nullptr, nullptr, bws,
+                                           workspace_bytes - 2 * xb, stream))
+            return rc;
+        void *tmp = xa;
+        xa = xc;
+        xc = tmp;
+    }
+    const float eps = blocks[0].norm_eps > 0.f ? blocks[0].norm_eps : 1e-6f;
+    if (linear_small_can_fold_norm(dt, B, vocab, dim, xa, lm_head)) {
+        if (int rc = launch_linear_small_norm(xa, lm_head, logits, B, vocab, dim, dt, 0, nullptr, norm_f_w, eps, st)) return rc;
+    } else {
+        if (int rc = launch_rmsnorm_rows(xa, norm_f_w, xc, B, dim, eps, dt, st)) return rc;
+        if (int rc = launch_linear_small_epi(xc, lm_head, logits, B, vocab, dim, dt, 0, nullptr, st)) return rc;
+    }
+    if (next_tokens) {
+        NSA_CHECK_ARG(argmax_rows_workspace(B, vocab) <= (size_t)B * 64 * 8, "model_decode_step: vocabulary too large for the in-call argmax");
+        return launch_argmax_rows(logits, next_tokens, B, vocab, dt, ws + need - up256((size_t)B * 64 * 8), st);
+    }
+    return NSA_OK;
+}
+
 }  // extern "C"

@@ -176,9 +176,65 @@ class TinyLM(nn.Module):
         x = x[:, -1:] if last_only else x
         return self.lm_head(self.norm_f(x))
 
-    def decode(self, tokens: torch.Tensor, caches: List[NSA_KV]) -> torch.Tensor:
-        """tokens [B,1] -> logits [B,1,vocab]; every layer appends the token to its cache"""
+    def decode(self, tokens: torch.Tensor, caches: List[NSA_KV], return_next: bool = False):
+        """tokens [B,1] -> logits [B,1,vocab] (and, with return_next, their argmax [B,1]); every layer appends the token to its cache.
+        Inference on the GPU = ONE native call for the whole stack (nsa_model_decode_step)."""
+        if self._native_decode_ok(tokens, caches):
+            return self._decode_native(tokens, caches, return_next)
         x = self.embed(tokens)
         for blk, kv in zip(self.blocks, caches):
             x = blk(x, kv, prefill=False)
-        return self.lm_head(self.norm_f(x))
+        logits = self.lm_head(self.norm_f(x))
+        return (logits, logits.argmax(-1)) if return_next else logits
+
+    def _native_decode_ok(self, tokens: torch.Tensor, caches: List[NSA_KV]) -> bool:
+        w = self.embed.weight
+        if not (tokens.is_cuda and tokens.shape[1] == 1 and w.is_cuda and self.norm_f.weight.dtype == w.dtype == self.lm_head.weight.dtype):
+            return False
+        probe = torch.empty((0, 1, w.shape[1]), dtype=w.dtype, device=w.device)
+        return all(blk.attn._native_ok(probe) and blk.norm1.weight.dtype == w.dtype for blk in self.blocks) and \
+            len({kv.t for kv in caches}) == 1 and len({kv._K_sel.shape[2] for kv in caches}) == 1
+
+    def _decode_native(self, tokens: torch.Tensor, caches: List[NSA_KV], return_next: bool):
+        from .selection_scorer import _DT  # noqa: F401
+
+        a0, kv0 = self.blocks[0].attn, caches[0]
+        t, B, dev = kv0.t, tokens.shape[0], tokens.device
+        if t + 1 > kv0._K_sel.shape[2]:
+            raise RuntimeError(f"NSA_KV capacity exceeded: {t}+1 > S_max={kv0.S_max}")
+        if kv0.meta.S_sel == 0:
+            meta = kv0.ensure_meta(max(t + 1, a0.l_sel))
+        elif t + 1 > kv0.meta.S_sel * a0.l_sel:
+            meta = kv0.ensure_meta(t + 1)
+        else:
+            meta = kv0.meta
+        L = _lib.lib()
+        n = len(self.blocks)
+        descs = [blk._block_desc() for blk in self.blocks]
+        key = (tuple(id(d) for d in descs), tuple(id(kv) for kv in caches), self.embed.weight.data_ptr(), self.lm_head.weight.data_ptr(),
+               self.norm_f.weight.data_ptr())
+        ctx = getattr(self, "_dec_ctx", None)
+        if ctx is None or ctx[0] != key:
+            barr = (_lib.NsaBlockDesc * n)(*descs)
+            karr = (_lib.NsaKvDesc * n)(*[blk.attn._kv_desc(kv) for blk, kv in zip(self.blocks, caches)])
+            ws = workspace(dev, L.nsa_model_decode_step_workspace(barr, n, B, karr[0].S_max) + 256, "model_decode")
+            wptr = (ws.data_ptr() + 255) & ~255
+            nxt = torch.empty((B, 1), dtype=torch.int32, device=dev)
+            ctx = self._dec_ctx = (key, barr, karr, ws, wptr, ws.numel() - (wptr - ws.data_ptr()), nxt)
+        _, barr, karr, _, wptr, wsize, nxt = ctx
+        cptr, crows, cvals = meta.device_csc(dev)
+        tok32 = tokens.reshape(B).to(torch.int32)
+        logits = torch.empty((B, 1, self.lm_head.out_features), dtype=self.embed.weight.dtype, device=dev)
+        rc = L.nsa_model_decode_step(barr, karr, n, tok32.data_ptr(), self.embed.weight.data_ptr(), self.norm_f.weight.data_ptr(),
+                                     self.lm_head.weight.data_ptr(), self.lm_head.out_features, logits.data_ptr(),
+                                     nxt.data_ptr() if return_next else None, t, cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(),
+                                     int(meta.S_sel), wptr, wsize, _stream(dev))
+        _lib.check(rc, "nsa_model_decode_step")
+        S_raw = t + 1
+        for blk, kv in zip(self.blocks, caches):
+            a = blk.attn
+            num_cmp = 0 if S_raw < a.l else (S_raw - a.l) // a.d + 1
+            kv.t, kv.n_cmp, kv.meta = S_raw, num_cmp, meta
+            kv.meta_seq_len = kv0.meta_seq_len
+            kv.append_reads(num_cmp, S_raw)
+        return (logits, nxt.to(torch.int64)) if return_next else logits

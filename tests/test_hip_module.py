@@ -439,3 +439,38 @@ def test_block_native_decode_matches_eager(dtype, tol, monkeypatch):
         assert err.max().item() <= tol
     else:
         assert err.median().item() <= tol and (err <= tol).float().mean().item() >= 0.9
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_decode_one_call_matches_per_block_path(dtype, monkeypatch):
+    """TinyLM.decode as ONE native call (embedding rows, 3 blocks, final norm folded into the LM head, argmax) against the eager
+    per-module path; greedy continuation must pick the same tokens in fp32"""
+    from nsa_vibe_amd.llama_block_nsa import TinyLM
+
+    torch.manual_seed(8)
+    lm = TinyLM(131, 128, 3, 4, 2, 64, 64, 32, 16, 64, 4, 64).cuda().to(dtype).eval()  # vocab 131: ragged LM-head tile
+    for B in (2, 5):  # folded-norm VALU head (B <= 2) and MFMA head with a partial column tile
+        S, n_dec = 90, 12
+        tok = torch.randint(0, 131, (B, S), device="cuda")
+        res = {}
+        for mode in ("native", "eager"):
+            if mode == "eager":
+                monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+            else:
+                monkeypatch.delenv("NSA_HIP_EAGER_TRAIN", raising=False)
+            caches = lm.new_caches(B, S + n_dec + 1, "cuda", dtype)
+            with torch.set_grad_enabled(mode == "eager"):
+                nxt = lm.prefill(tok, caches).argmax(-1)
+                toks, lgs = [], []
+                for _ in range(n_dec):
+                    lg, nx = lm.decode(nxt, caches, return_next=True)
+                    lgs.append(lg.detach().float())
+                    toks.append(nx)
+                    nxt = nx if dtype == torch.float32 else res["native"][1][len(toks) - 1] if mode == "eager" else nx
+            res[mode] = (torch.cat(lgs, dim=1), toks)
+        err = (res["native"][0] - res["eager"][0]).abs().amax(dim=-1)
+        if dtype == torch.float32:
+            assert err.max().item() <= 5e-4
+            assert all(torch.equal(a, b) for a, b in zip(res["native"][1], res["eager"][1]))
+        else:
+            assert err.median().item() <= 0.15

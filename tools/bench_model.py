@@ -56,13 +56,13 @@ with torch.no_grad():
     print(f"prefill m7c_125m S={S} B={B}: {best * 1e3:.2f} ms  ({B * S / best / 1e6:.2f} M tok/s)")
     nxt = logits.argmax(-1)
     for _ in range(8):
-        nxt = lm.decode(nxt, caches).argmax(-1)
+        nxt = lm.decode(nxt, caches, return_next=True)[1]
     dt = 1e9
     for _ in range(max(1, steps // 8)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(8):
-            nxt = lm.decode(nxt, caches).argmax(-1)
+            nxt = lm.decode(nxt, caches, return_next=True)[1]
         torch.cuda.synchronize()
         dt = min(dt, (time.perf_counter() - t0) / 8)
     print(f"decode m7c_125m ctx={S} B={B}: {dt * 1e3:.3f} ms/token-step  ({B / dt:.0f} tok/s)")
