@@ -20,8 +20,9 @@ _META_CACHE: dict = {}
 
 class NSA_KV:
     def __init__(self, B: int, G: int, d_k: int, d_v: int, S_max: int, l: int, d: int, l_sel: int, n_sel: int, w: int,
-                 device, dtype):
+                 device, dtype, auto_grow: bool = True):
         self.B, self.G, self.d_k, self.d_v, self.S_max = B, G, d_k, d_v, S_max
+        self.auto_grow = auto_grow
         self.l, self.d, self.l_sel, self.n_sel, self.w = l, d, l_sel, n_sel, w
         n_cmp_max = 0 if S_max < l else (S_max - l) // d + 1
         mk = lambda n, dim: torch.empty((B, G, max(n, 1), dim), device=device, dtype=dtype)  # noqa: E731
@@ -73,12 +74,41 @@ class NSA_KV:
     def V_cmp(self):
         return self._V_cmp[:, :, : self.n_cmp]
 
+    # ---- capacity -------------------------------------------------------------------------
+    def reserve(self, S_max: int) -> None:
+        """grow the buffers to hold S_max tokens, keeping what is stored (the one O(S) copy the reference pays on every step,
+        kv_cache.py:28-30, paid here once per doubling).  Cached native descriptors of the old buffers are dropped."""
+        if S_max <= self._K_sel.shape[2]:
+            return
+        n_cmp_max = 0 if S_max < self.l else (S_max - self.l) // self.d + 1
+
+        def grow(buf, n, used):
+            new = torch.empty((self.B, self.G, max(n, 1), buf.shape[3]), device=buf.device, dtype=buf.dtype)
+            if used:
+                new[:, :, :used] = buf[:, :, :used]
+            return new
+
+        for name in ("_K_sel", "_V_sel", "_K_win", "_V_win", "_K_raw", "_V_raw"):
+            setattr(self, name, grow(getattr(self, name), S_max, self.t))
+        self._K_cmp, self._V_cmp = grow(self._K_cmp, n_cmp_max, self.n_cmp), grow(self._V_cmp, n_cmp_max, self.n_cmp)
+        self.S_max = S_max
+        for attr in ("_desc", "_dec_ctx", "_blk_ctx"):
+            self.__dict__.pop(attr, None)
+
+    def ensure_capacity(self, n_tokens: int) -> None:
+        """room for n_tokens in total: grows geometrically (auto_grow) or raises"""
+        cap = self._K_sel.shape[2]
+        if n_tokens <= cap:
+            return
+        if not self.auto_grow:
+            raise RuntimeError(f"NSA_KV capacity exceeded: {n_tokens} > S_max={self.S_max}")
+        self.reserve(max(n_tokens, 2 * cap))
+
     # ---- updates --------------------------------------------------------------------------
     def write_tokens(self, K_sel, V_sel, K_win, V_win, K_raw, V_raw) -> None:
         """append S new tokens ([B,G,S,D] each) at position t (update_selection_raw/update_window/append_cmp_raw)."""
         S = K_sel.shape[2]
-        if self.t + S > self.S_max:
-            raise RuntimeError(f"NSA_KV capacity exceeded: {self.t}+{S} > S_max={self.S_max}")
+        self.ensure_capacity(self.t + S)
         sl = slice(self.t, self.t + S)
         self._K_sel[:, :, sl], self._V_sel[:, :, sl] = K_sel, V_sel
         self._K_win[:, :, sl], self._V_win[:, :, sl] = K_win, V_win

@@ -113,8 +113,7 @@ class LlamaBlockNSA(nn.Module):
     def _decode_native(self, x: torch.Tensor, kv: NSA_KV) -> torch.Tensor:
         a = self.attn
         t, B, dev = kv.t, x.shape[0], x.device
-        if t + 1 > kv._K_sel.shape[2]:
-            raise RuntimeError(f"NSA_KV capacity exceeded: {t}+1 > S_max={kv.S_max}")
+        kv.ensure_capacity(t + 1)
         if kv.meta.S_sel == 0:
             kv.ensure_meta(max(t + 1, a.l_sel))
         elif t + 1 > kv.meta.S_sel * a.l_sel:
@@ -200,8 +199,8 @@ class TinyLM(nn.Module):
 
         a0, kv0 = self.blocks[0].attn, caches[0]
         t, B, dev = kv0.t, tokens.shape[0], tokens.device
-        if t + 1 > kv0._K_sel.shape[2]:
-            raise RuntimeError(f"NSA_KV capacity exceeded: {t}+1 > S_max={kv0.S_max}")
+        for kv in caches:
+            kv.ensure_capacity(t + 1)
         if kv0.meta.S_sel == 0:
             meta = kv0.ensure_meta(max(t + 1, a0.l_sel))
         elif t + 1 > kv0.meta.S_sel * a0.l_sel:
@@ -211,7 +210,7 @@ class TinyLM(nn.Module):
         L = _lib.lib()
         n = len(self.blocks)
         descs = [blk._block_desc() for blk in self.blocks]
-        key = (tuple(id(d) for d in descs), tuple(id(kv) for kv in caches), self.embed.weight.data_ptr(), self.lm_head.weight.data_ptr(),
+        key = (tuple(id(d) for d in descs), tuple((id(kv), kv._K_sel.data_ptr()) for kv in caches), self.embed.weight.data_ptr(), self.lm_head.weight.data_ptr(),
                self.norm_f.weight.data_ptr())
         ctx = getattr(self, "_dec_ctx", None)
         if ctx is None or ctx[0] != key:

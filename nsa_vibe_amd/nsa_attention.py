@@ -367,8 +367,7 @@ class NSAAttention(nn.Module):
         from .selection_scorer import batched_ranges_width
 
         B, S, _ = x.shape
-        if S > kv._K_sel.shape[2]:
-            raise RuntimeError(f"NSA_KV capacity exceeded: {S} > S_max={kv.S_max}")
+        kv.ensure_capacity(S)
         L, dev = _lib.lib(), x.device
         desc, W_qkv = self._layer_desc()
         kd = self._kv_desc(kv)
@@ -398,8 +397,7 @@ class NSAAttention(nn.Module):
         """training forward: one fused projection GEMM, then every stage is a differentiable native op (the attention branches
         with their backward kernels, RoPE/append, pooling and gate/combine with theirs)"""
         B, S, _ = x.shape
-        if S > kv._K_sel.shape[2]:
-            raise RuntimeError(f"NSA_KV capacity exceeded: {S} > S_max={kv.S_max}")
+        kv.ensure_capacity(S)
         W_qkv = torch.cat([getattr(self, n).weight for n in self._QKV], dim=0)
         proj = F.linear(x, W_qkv)
         Q, K_sel, V_sel, K_win, V_win, K_raw, V_raw = _RopeAppendFn.apply(proj, self, kv, S)
@@ -424,8 +422,7 @@ class NSAAttention(nn.Module):
     def _decode_native(self, x: torch.Tensor, kv: NSA_KV):
         """the whole decode step in one native call (nsa_layer_decode_step): ~15 kernel launches, no host sync"""
         t, B, dev = kv.t, x.shape[0], x.device
-        if t + 1 > kv._K_sel.shape[2]:
-            raise RuntimeError(f"NSA_KV capacity exceeded: {t}+1 > S_max={kv.S_max}")
+        kv.ensure_capacity(t + 1)
         if kv.meta.S_sel == 0:  # block metadata refresh policy of the reference (:606-632)
             kv.ensure_meta(max(t + 1, self.l_sel))
         elif t + 1 > kv.meta.S_sel * self.l_sel:

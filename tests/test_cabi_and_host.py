@@ -197,3 +197,28 @@ def test_llama_block_state_dict_matches_reference():
     lm = TinyLM(100, 64, 2, 4, 2, 16, 16, 8, 4, 8, 4, 16)
     keys = set(lm.state_dict().keys())
     assert {"embed.weight", "norm_f.weight", "lm_head.weight", "blocks.0.attn.W_Q.weight", "blocks.1.mlp.fc2.weight"} <= keys
+
+
+def test_kv_cache_grows_in_place_of_the_reference_cat(nv):
+    """NSA_KV.reserve / ensure_capacity: contents kept, views keep the reference's shapes, cached native descriptors dropped;
+    auto_grow=False restores the hard limit"""
+    from nsa_vibe_amd.kv_cache import NSA_KV
+
+    kv = NSA_KV(2, 2, 8, 8, 20, 4, 2, 8, 2, 16, "cpu", torch.float32)
+    tok = lambda n: [torch.randn(2, 2, n, 8) for _ in range(6)]  # noqa: E731
+    first = tok(20)
+    kv.write_tokens(*first)
+    kv.write_compressed(torch.ones(2, 2, 9, 8), torch.ones(2, 2, 9, 8), at=0)
+    kv._desc = kv._dec_ctx = object()
+    more = tok(5)
+    kv.write_tokens(*more)  # 25 > 20: doubles
+    assert kv.S_max == 40 and kv._K_sel.shape[2] == 40 and kv._K_cmp.shape[2] == (40 - 4) // 2 + 1
+    assert not hasattr(kv, "_desc") and not hasattr(kv, "_dec_ctx")
+    assert torch.equal(kv.K_sel, torch.cat([first[0], more[0]], dim=2)) and torch.equal(kv.V_cmp_raw_seq[:, :, :20], first[5])
+    assert kv.K_cmp.shape[2] == 9 and bool((kv.K_cmp == 1).all())
+    assert kv.K_win.shape[2] == 16
+    kv.reserve(30)  # never shrinks
+    assert kv.S_max == 40
+    fixed = NSA_KV(1, 1, 8, 8, 4, 4, 2, 8, 2, 16, "cpu", torch.float32, auto_grow=False)
+    with pytest.raises(RuntimeError, match="capacity exceeded"):
+        fixed.write_tokens(*[torch.zeros(1, 1, 5, 8) for _ in range(6)])

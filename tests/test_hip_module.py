@@ -474,3 +474,36 @@ def test_model_decode_one_call_matches_per_block_path(dtype, monkeypatch):
             assert all(torch.equal(a, b) for a, b in zip(res["native"][1], res["eager"][1]))
         else:
             assert err.median().item() <= 0.15
+
+
+def test_decode_past_the_reserved_capacity_grows_the_cache():
+    """a cache created too small doubles itself (layer, block and whole-model decode paths) and the outputs equal those of a cache
+    that was large enough from the start"""
+    from nsa_vibe_amd.llama_block_nsa import TinyLM
+
+    torch.manual_seed(21)
+    lm = TinyLM(97, 128, 2, 4, 2, 64, 64, 32, 16, 64, 4, 64).cuda().float().eval()
+    B, S, n_dec = 2, 70, 40
+    tok = torch.randint(0, 97, (B, S), device="cuda")
+    outs = {}
+    with torch.no_grad():
+        for name, cap in (("small", S + 3), ("large", 256)):
+            caches = lm.new_caches(B, cap, "cuda", torch.float32)
+            nxt = lm.prefill(tok, caches).argmax(-1)
+            lgs = []
+            for _ in range(n_dec):
+                lg, nxt = lm.decode(nxt, caches, return_next=True)
+                lgs.append(lg)
+            outs[name] = torch.cat(lgs, dim=1)
+            assert caches[0].t == S + n_dec and caches[0].S_max >= S + n_dec
+        assert torch.equal(outs["small"], outs["large"])
+        # the single-layer path
+        attn = lm.blocks[0].attn
+        x = torch.randn(B, S, 128, device="cuda")
+        ys = {}
+        for name, cap in (("small", S), ("large", 256)):
+            kv = attn.new_kv(B, cap, "cuda", torch.float32)
+            attn(x, kv, prefill=True)
+            y = [attn(x[:, i: i + 1], kv, prefill=False)[0] for i in range(10)]
+            ys[name] = torch.cat(y, dim=1)
+        assert torch.equal(ys["small"], ys["large"])
