@@ -17,6 +17,8 @@
  *   nsa_sel_attn_fwd           sel_forward(Q,K,V,ranges)            nsa/kernels/cuda_sel_kernel/sel_cuda.cpp:28-73
  *                              selection_attention_cuda             nsa/kernels/cuda_sel_kernel/__init__.py:47-68
  *                              grouped_selection_attention_masked   nsa/core/attention_kernels.py:705-772 (semantics)
+ *   nsa_sel_attn_first_key_parity  grouped_selection_attention_packed / grouped_selection_attention (parity mode)
+ *                                                                   nsa/core/attention_kernels.py:273-388, 181-226
  *   nsa_sel_attn_bwd           analytic backward / autograd of the masked SDPA
  *                                                                   nsa/kernels/triton_sel_kernel/__init__.py:125-231
  *   nsa_sel_scores             compute_pcmp_all + map_pcmp_to_pslc_batched + .sum(dim=3)
@@ -87,6 +89,15 @@ NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const 
                      int64_t k_stride_b, int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b,
                      int64_t v_stride_g, int64_t v_stride_s, int dtype, float scale, int variant,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Opt-in PARITY MODE of the reference's default packed / gather executors (grouped_selection_attention_packed,
+ * nsa/core/attention_kernels.py:273-388; grouped_selection_attention, :181-226): they call SDPA with is_causal=True and a single
+ * query, so the query sees only the first gathered key and every head's output is V[b,g,start of the first non-empty range]
+ * (slot order; ranges clamped to [0,S_kv] as everywhere here), zeros for a row without a range.  Not the semantics of the
+ * selected branch -- kept so that outputs of the reference's default routing can be reproduced bit for bit. */
+NSA_API int nsa_sel_attn_first_key_parity(const void *V, const int32_t *ranges, void *O, int B, int S, int G, int h, int Dv,
+                                  int S_kv, int n_ranges, int64_t v_stride_b, int64_t v_stride_g, int64_t v_stride_s,
+                                  int dtype, void *stream);
 
 /* Backward.  dO like O; dQ like Q (dtype); dK/dV are fp32 [B,G,S_kv,D] contiguous, fully written by the callee.
  * O and lse come from the forward.

@@ -16,6 +16,7 @@ from .selection_attention import (  # noqa: F401
     grouped_selection_attention_masked,
     hip_sel_available,
     select_and_attend,
+    selection_attention_first_key_parity,
     selection_attention_hip,
     selection_decode_step,
 )

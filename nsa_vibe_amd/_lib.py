@@ -48,6 +48,7 @@ SIGNATURES = {
     "nsa_hip_device_check": (_i, [_i, C.POINTER(_i), C.POINTER(_sz)]),
     "nsa_sel_attn_fwd_workspace": (_sz, [_i] * 8),
     "nsa_sel_attn_fwd": (_i, [_vp] * 6 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
+    "nsa_sel_attn_first_key_parity": (_i, [_vp] * 3 + [_i] * 7 + [_i64] * 3 + [_i, _vp]),
     "nsa_sel_attn_bwd_workspace": (_sz, [_i] * 9),
     "nsa_sel_attn_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_band_attn_fwd_workspace": (_sz, [_i] * 7),

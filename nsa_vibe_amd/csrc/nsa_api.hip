@@ -49,6 +49,9 @@ bool scores_mfma_supported(int, int, int, int, int, int);
 int launch_sel_scores_mfma(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t, int,
                            int, int, float, int, hipStream_t);
 
+int launch_sel_first_key(const void *, const int32_t *, void *, int64_t, int, int, int, int, int, int, int64_t, int64_t, int64_t, int,
+                         hipStream_t);
+
 static bool dtype_ok(int dt) { return dt == NSA_DT_F32 || dt == NSA_DT_BF16 || dt == NSA_DT_F16; }
 
 }  // namespace nsa
@@ -145,6 +148,22 @@ int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t 
                      void *workspace, size_t workspace_bytes, void *stream) {
     return sel_attn_fwd_impl(Q, K, V, ranges, O, lse, B, S, G, h, Dk, Dv, S_kv, n_ranges, ksb, ksg, kss, vsb, vsg, vss, dtype, scale, variant,
                              workspace, workspace_bytes, stream, 0, nullptr);
+}
+
+int nsa_sel_attn_first_key_parity(const void *V, const int32_t *ranges, void *O, int B, int S, int G, int h, int Dv, int S_kv, int n_ranges,
+                                  int64_t vsb, int64_t vsg, int64_t vss, int dtype, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_attn_first_key_parity: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dv >= 1 && S_kv >= 0 && n_ranges >= 0, "sel_attn_first_key_parity: negative size");
+    NSA_CHECK_ARG(n_ranges <= 64, "sel_attn_first_key_parity: at most 64 ranges per row are supported (got %d)", n_ranges);
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    NSA_CHECK_ARG(O && (ranges || n_ranges == 0) && (V || S_kv == 0), "sel_attn_first_key_parity: null pointer");
+    const int esz = dtype == NSA_DT_F32 ? 4 : 2;
+    if (S_kv == 0 || n_ranges == 0) {
+        NSA_HIP_TRY(hipMemsetAsync(O, 0, (size_t)R * h * Dv * esz, (hipStream_t)stream));
+        return NSA_OK;
+    }
+    return launch_sel_first_key(V, ranges, O, R, S, G, h, Dv, n_ranges, S_kv, vsb, vsg, vss, esz, (hipStream_t)stream);
 }
 
 size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant) {

@@ -319,4 +319,48 @@ int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_
     return NSA_ERR_INVALID;
 }
 
+// ---- parity mode of the reference's packed / gather executors (attention_kernels.py:181-226, 273-388) ----------------------
+// Those call SDPA with is_causal=True and ONE query, which lets the query see only the first gathered key: every head's output is
+// V[b,g,first token of the first non-empty range] (slot order), zeros when the row has no range.  Kept as an opt-in parity mode.
+template <typename E>
+__global__ __launch_bounds__(256) void sel_first_key_kernel(const E *__restrict__ V, const int32_t *__restrict__ ranges, E *__restrict__ O,
+                                                            int64_t R, int S, int G, int h, int Dv, int n, int S_kv, int64_t vsb, int64_t vsg,
+                                                            int64_t vss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int g = (int)(row % G);
+    const int64_t b = row / ((int64_t)S * G);
+    int s = 0, e = 0;
+    if (lane < n) {
+        s = ranges[(row * n + lane) * 2 + 0];
+        e = ranges[(row * n + lane) * 2 + 1];
+        s = min(max(s, 0), S_kv);
+        e = min(max(e, s), S_kv);
+    }
+    const unsigned long long live = __ballot(e > s);
+    E *o = O + row * (int64_t)h * Dv;
+    if (live == 0ull) {
+        for (int i = lane; i < h * Dv; i += 64) o[i] = E(0);
+        return;
+    }
+    const int tok = __shfl(s, __ffsll((long long)live) - 1, 64);
+    const E *v = V + b * vsb + g * vsg + (int64_t)tok * vss;
+    for (int i = lane; i < h * Dv; i += 64) o[i] = v[i % Dv];
+}
+
+int launch_sel_first_key(const void *V, const int32_t *ranges, void *O, int64_t R, int S, int G, int h, int Dv, int n, int S_kv, int64_t vsb,
+                         int64_t vsg, int64_t vss, int esz, hipStream_t st) {
+    const unsigned grid = (unsigned)((R + 3) / 4);
+    if (esz == 4)
+        hipLaunchKernelGGL(sel_first_key_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, (const uint32_t *)V, ranges, (uint32_t *)O, R, S, G, h,
+                           Dv, n, S_kv, vsb, vsg, vss);
+    else
+        hipLaunchKernelGGL(sel_first_key_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t *)V, ranges, (uint16_t *)O, R, S, G, h,
+                           Dv, n, S_kv, vsb, vsg, vss);
+    NSA_LAUNCH_CHECK("sel_first_key");
+    return NSA_OK;
+}
+
+
 }  // namespace nsa

@@ -108,6 +108,24 @@ def selection_attention_hip(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, r
     return (O, lse) if return_lse else O
 
 
+def selection_attention_first_key_parity(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, ranges: torch.Tensor) -> torch.Tensor:
+    """PARITY MODE, opt-in: what the reference's default packed / gather executors return (grouped_selection_attention_packed,
+    attention_kernels.py:273-388; grouped_selection_attention, :181-226).  Their SDPA call is `is_causal=True` with one query, so only
+    the first gathered key is visible and O[b,t,g,h,:] = V[b,g,start of the first non-empty range] for every head (zeros when the row
+    has none).  Same executor signature as selection_attention_hip; Q and K do not influence the result.  Inference only."""
+    dev = _need_gpu(Q, K, V)
+    if torch.is_grad_enabled() and V.requires_grad:
+        raise RuntimeError("selection_attention_first_key_parity is an inference-only parity mode")
+    B, S, G, h, _ = Q.shape
+    S_kv, Dv = V.shape[2], V.shape[3]
+    Vv, rg = _prep_kv(V), _prep_ranges(ranges)
+    O = torch.empty((B, S, G, h, Dv), dtype=V.dtype, device=dev)
+    rc = _lib.lib().nsa_sel_attn_first_key_parity(Vv.data_ptr(), rg.data_ptr(), O.data_ptr(), B, S, G, h, Dv, S_kv, rg.shape[3],
+                                                  Vv.stride(0), Vv.stride(1), Vv.stride(2), _DT[V.dtype], _stream(dev))
+    _lib.check(rc, "nsa_sel_attn_first_key_parity")
+    return O
+
+
 def selection_decode_step(Q: torch.Tensor, K_cmp: torch.Tensor, K: torch.Tensor, V: torch.Tensor, meta, n_top: int, t_token: int,
                           *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
                           ranges_out: Optional[torch.Tensor] = None):

@@ -247,6 +247,26 @@ def batched_causal_attention_compressed(Q, K_cmp, V_cmp, l: int, d: int, *, t0: 
     return band_attention(Q, K_cmp, V_cmp, t0=t0, a=int(l), dd=int(d), c=1, scale=scale)
 
 
+def sel_attention_first_key_parity(Q, V, ranges) -> np.ndarray:
+    """PARITY MODE of the reference's packed / gather executors (attention_kernels.py:181-226, 273-388): SDPA(is_causal=True) with one
+    query sees only the first gathered key, so every head returns V at the start of the first non-empty range (slot order); a row
+    without a range stays zero.  Pure numpy (small cases)."""
+    V, r = np.asarray(V), np.asarray(ranges)
+    B, S, G, h = np.asarray(Q).shape[:4]
+    S_kv = V.shape[2]
+    O = np.zeros((B, S, G, h, V.shape[3]), dtype=V.dtype)
+    for b in range(B):
+        for t in range(S):
+            for g in range(G):
+                for s0, e0 in r[b, t, g]:
+                    s0 = min(max(int(s0), 0), S_kv)
+                    e0 = min(max(int(e0), s0), S_kv)
+                    if e0 > s0:
+                        O[b, t, g] = V[b, g, s0]
+                        break
+    return O
+
+
 def normalise_ranges(r: np.ndarray) -> list:
     """Drop e<=s entries (SURVEY 7 hard part (c)); returns nested lists of (s,e) per row."""
     r = np.asarray(r)

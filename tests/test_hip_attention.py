@@ -328,3 +328,29 @@ def test_select_and_attend_equals_separate_calls(nv, mode, B, S, G, dtype):
     torch.cuda.synchronize()
     assert r.shape == r_ref.shape and torch.equal(r, r_ref)
     assert torch.equal(O, O_ref) and torch.equal(lse, lse_ref)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_first_key_parity_mode_matches_reference_default_executors(nv, orc, name, dtype):
+    """opt-in parity mode == grouped_selection_attention_packed / grouped_selection_attention of the reference (g15, bit-exact: the
+    output is a copy of V rows), also through a strided cache view and with int64 ranges"""
+    g = load_golden("g15_first_key_" + name)
+    Q, K, V = (torch.from_numpy(g[k]).cuda().to(dtype) for k in ("Q", "K", "V"))
+    rg = torch.from_numpy(g["ranges"]).cuda()
+    want = torch.from_numpy(g["O"]).cuda().to(dtype)
+    assert torch.equal(nv.selection_attention_first_key_parity(Q, K, V, rg), want)
+    cache = torch.zeros(V.shape[0], V.shape[1], V.shape[2] + 13, V.shape[3], device="cuda", dtype=dtype)
+    cache[:, :, : V.shape[2]] = V
+    r64 = rg.to(torch.int64)
+    keep = r64.clone()
+    assert torch.equal(nv.selection_attention_first_key_parity(Q, K, cache[:, :, : V.shape[2]], r64), want)
+    assert torch.equal(r64, keep)
+    # it is NOT the selected branch: the semantic executor differs wherever a row gathers more than one key
+    sem = nv.selection_attention_hip(Q, K, V, rg)
+    assert (sem.float() - want.float()).abs().max().item() > 0.1
+    # out-of-range ranges are clamped like everywhere else
+    S_kv = V.shape[2]
+    wild = torch.tensor([[-5, -1], [S_kv - 2, S_kv + 100]], dtype=torch.int32, device="cuda").expand(*rg.shape[:3], 2, 2).contiguous()
+    out = nv.selection_attention_first_key_parity(Q, K, V, wild)
+    assert torch.equal(out, V[:, :, S_kv - 2][:, None, :, None, :].expand_as(out))

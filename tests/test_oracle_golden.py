@@ -202,3 +202,10 @@ def test_g13_compressed(orc, name):
     assert np.abs(O - g["O"]).max() <= 2e-5
     if name == "b":
         assert not O.any()
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_g15_first_key_parity_mode(orc, name):
+    """oracle restatement of the reference's packed / gather executors (attention_kernels.py:181-226, 273-388): V at the first key"""
+    g = load_golden("g15_first_key_" + name)
+    assert np.array_equal(orc.sel_attention_first_key_parity(g["Q"], g["V"], g["ranges"]), g["O"])
