@@ -341,6 +341,69 @@ def train_mode(nv, args, dist, world, rank, device):
         dist.destroy_process_group()
 
 
+def train_model_mode(nv, args, dist, world, rank, device):
+    """BASELINE config 5: the m7c_125m TinyLM (12 x LlamaBlockNSA, dim 768, GPT-2 vocabulary as configs/m7c_125m_80g.yaml names it) trained
+    on synthetic random tokens (train_showcase.py:1222): forward, cross-entropy, backward, gradient clipping at 1.0 and a fused AdamW
+    step (lr 2e-4, weight decay 0.01), bf16 weights.  Every rank B sequences; DistributedDataParallel overlaps the bucketed RCCL
+    all-reduce with the backward.  time = max over ranks, value = whole-job tokens/s."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from nsa_vibe_amd.llama_block_nsa import TinyLM
+
+    B, S, V = args.batch, args.seq, args.vocab
+    torch.manual_seed(0)  # identical initial weights on every rank
+    lm = TinyLM(V, 768, args.layers, 12, G, D, D, L_CMP, D_CMP, L_SEL, N_SEL, 512, selector="batched").to(device).to(torch.bfloat16).train()
+    model = DDP(lm, device_ids=[device.index], bucket_cap_mb=25, gradient_as_bucket_view=True) if dist is not None else lm
+    opt = torch.optim.AdamW(lm.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
+    g = torch.Generator(device=device)
+    g.manual_seed(1337 + rank)
+    tok = torch.randint(0, V, (B, S + 1), device=device, generator=g)
+    x, y = tok[:, :-1].contiguous(), tok[:, 1:].contiguous()
+    loss_box = [None]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits.view(-1, V).float(), y.view(-1))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(lm.parameters(), 1.0)
+        opt.step()
+        loss_box[0] = loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    first = float(loss_box[0]) if loss_box[0] is not None else float("nan")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        n_par = sum(p.numel() for p in lm.parameters())
+        print(json.dumps({
+            "metric": "m7c_125m_train_tok_per_s", "value": world * B * S / (elapsed / args.steps), "unit": "tok/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"m7c_125m TinyLM ({args.layers} NSA blocks, dim 768, vocab {V}, {n_par / 1e6:.1f} M parameters): forward + "
+                                   f"cross-entropy + backward + clip + fused AdamW, S={S}, B={B} per GPU, random tokens and weights",
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world} (DistributedDataParallel over RCCL)"},
+            "loss_after_warmup": first, "loss_last": float(loss_box[0]),
+            "peak_mem_GiB": torch.cuda.max_memory_allocated(device) / 2 ** 30}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +415,11 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="instead of the hot path: forward+backward of the whole NSAAttention layer under DistributedDataParallel "
                          "(BASELINE config 5: gradient all-reduce over RCCL/xGMI, batch sharded over the ranks)")
+    ap.add_argument("--train-model", action="store_true",
+                    help="instead of the hot path: one optimiser step of the whole m7c_125m TinyLM under DistributedDataParallel "
+                         "(BASELINE config 5 in full: 12 NSA blocks, cross-entropy, clip, fused AdamW)")
+    ap.add_argument("--layers", type=int, default=12, help="--train-model: number of blocks")
+    ap.add_argument("--vocab", type=int, default=50257, help="--train-model: vocabulary (GPT-2, as configs/m7c_125m_80g.yaml)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -372,6 +440,8 @@ def main():
     import nsa_vibe_amd as nv  # fails loudly if libnsa_sel_hip.so is missing
 
     B, S = args.batch, args.seq
+    if args.train_model:
+        return train_model_mode(nv, args, dist, world, rank, device)
     if args.train:
         return train_mode(nv, args, dist, world, rank, device)
     meta, Q, Kc, K, V = make_inputs(nv, B, S, device, 1234 + rank)
