@@ -4,6 +4,7 @@ setup of the reference's test_equiv_full_coverage.py:72), prefill in both select
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden
 
@@ -507,3 +508,34 @@ def test_decode_past_the_reserved_capacity_grows_the_cache():
             y = [attn(x[:, i: i + 1], kv, prefill=False)[0] for i in range(10)]
             ys[name] = torch.cat(y, dim=1)
         assert torch.equal(ys["small"], ys["large"])
+
+
+def test_tiny_lm_training_steps_reduce_the_loss_like_the_eager_composition(monkeypatch):
+    """a few AdamW steps of a 2-block TinyLM on a fixed random batch (the loop of bench.py --train-model): the native training route
+    and the eager composition of the same HIP attention ops start from the same loss, and the loss falls"""
+    from nsa_vibe_amd.llama_block_nsa import TinyLM
+
+    losses = {}
+    for mode in ("native", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        else:
+            monkeypatch.delenv("NSA_HIP_EAGER_TRAIN", raising=False)
+        torch.manual_seed(5)
+        lm = TinyLM(97, 128, 2, 4, 2, 64, 64, 32, 16, 64, 4, 64, selector="batched").cuda().to(torch.bfloat16).train()
+        opt = torch.optim.AdamW(lm.parameters(), lr=2e-3, weight_decay=0.01)
+        tok = torch.randint(0, 97, (2, 161), device="cuda")
+        x, y = tok[:, :-1].contiguous(), tok[:, 1:].contiguous()
+        ls = []
+        for _ in range(8):
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(lm(x).view(-1, 97).float(), y.view(-1))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(lm.parameters(), 1.0)
+            opt.step()
+            ls.append(float(loss.detach()))
+        losses[mode] = ls
+    assert abs(losses["native"][0] - losses["eager"][0]) < 0.02
+    for ls in losses.values():
+        assert all(np.isfinite(ls)) and ls[-1] < ls[0] - 0.2
+    assert abs(losses["native"][-1] - losses["eager"][-1]) < 0.15
