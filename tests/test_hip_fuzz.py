@@ -199,3 +199,43 @@ def test_fuzz_module_native_vs_eager(seed, monkeypatch):
         assert (a - e).abs().max().item() <= 1e-3 * max(1.0, e.abs().max().item()), cfg
     # decode ranges: identical sets of selected tokens (the eager selector may order equal-score picks differently only on exact ties)
     assert torch.equal(outs["native"][2].reshape(-1, 2), outs["eager"][2].reshape(-1, 2)), cfg
+
+
+@pytest.mark.parametrize("seed", SEEDS_MOD)
+def test_fuzz_training_gradients_native_vs_eager(seed, monkeypatch):
+    """random layer geometries, fp32: gradients of the native training route (native backward kernels behind autograd Functions) against
+    torch autograd through the eager composition"""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    rng = np.random.default_rng(9700 + seed)
+    G = int(rng.choice([1, 2, 3]))
+    h = int(rng.choice([1, 2, 4, 6]))
+    dk = int(rng.choice([16, 32, 64, 64]))
+    dv = dk if rng.random() < 0.7 else int(rng.choice([16, 32, 64]))
+    d = int(rng.choice([2, 4, 8, 16]))
+    l = d * int(rng.choice([1, 2, 4]))
+    l_sel = d * int(rng.choice([2, 4, 8]))
+    n_sel = int(rng.integers(3, 8))
+    w = int(rng.integers(1, 100))
+    dim = int(rng.choice([64, 96]))
+    B, S = int(rng.integers(1, 3)), int(rng.integers(2, 200))
+    cfg = dict(G=G, h=h, dk=dk, dv=dv, l=l, d=d, l_sel=l_sel, n_sel=n_sel, w=w, dim=dim, B=B, S=S)
+    torch.manual_seed(seed)
+    m = NSAAttention(dim, G * h, G, dk, dv, l=l, d=d, l_sel=l_sel, n_sel=n_sel, w=w, selector="batched").cuda().float().train()
+    x0 = torch.randn(B, S, dim, device="cuda")
+    go = torch.randn(B, S, dim, device="cuda")
+    grads = {}
+    for mode in ("native", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        else:
+            monkeypatch.delenv("NSA_HIP_EAGER_TRAIN", raising=False)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y, _ = m(x, m.new_kv(B, S, "cuda", torch.float32), prefill=True)
+        y.backward(go)
+        grads[mode] = [y.detach(), x.grad.detach()] + [torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
+                                                        for p in m.parameters()]  # S < l: the compressed projections see no gradient
+    for a, e in zip(grads["native"], grads["eager"]):
+        assert torch.isfinite(a).all(), cfg
+        assert (a - e).abs().max().item() <= 2e-3 * max(1.0, e.abs().max().item()), cfg
