@@ -465,6 +465,11 @@ int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st) 
                   "MFMA kernel: Q/K/V must be 16-byte aligned");
     NSA_CHECK_ARG((int64_t)P.S_kv * P.kss * 2 < ((int64_t)1 << 31) && (int64_t)P.S_kv * P.vss * 2 < ((int64_t)1 << 31),
                   "MFMA kernel: one (b,g) K/V slab must be smaller than 2 GiB (buffer addressing)");
+    if (!(P.part != nullptr && P.nsplit > 1)) {  // many rows: one wave per tile of 48/h query rows, K/V tiles shared by the rows
+        int nt = 1;
+        const int tpw = sel_attn_rows_tpw(dtype, P.h, P.Dk, P.Dv, P.S, P.S_kv, P.n, P.R, &nt);
+        if (tpw > 0) return launch_sel_attn_rows_mfma(P, dtype, tpw, nt, st);
+    }
     if (dtype == NSA_DT_BF16) return P.Dk == 64 ? launch_mfma_t<__bf16, 64>(P, st) : launch_mfma_t<__bf16, 128>(P, st);
     return P.Dk == 64 ? launch_mfma_t<_Float16, 64>(P, st) : launch_mfma_t<_Float16, 128>(P, st);
 }

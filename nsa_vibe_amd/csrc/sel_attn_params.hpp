@@ -23,6 +23,7 @@ struct SelAttnParams {
     int defer_combine;  // split-KV: leave the partial records for the caller's own combine pass
     int fuse_select;    // the kernel first selects the row's ranges from its group scores (select = const SelectParams *, host)
     const void *select;
+    int tpw, nw, wave_lds;  // query-tile form (sel_attn_rows_mfma.hip): rows per wave, 32-tile bitmap words per row, LDS bytes per wave
 };
 
 struct SelAttnBwdParams {
@@ -81,6 +82,9 @@ int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_
 bool sel_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
 int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st);
 size_t sel_attn_mfma_workspace(int64_t R, int h, int Dv, int *nsplit_out);
+// query-tile form: rows per wave for this shape, 0 = not covered (use the one-row-per-wave kernel)
+int sel_attn_rows_tpw(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int *nt);
+int launch_sel_attn_rows_mfma(const SelAttnParams &P, int dtype, int tpw, int nt, hipStream_t st);
 bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv);
 size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_kv);
 int launch_sel_attn_bwd_mfma(const SelAttnBwdParams &P, int dtype, float *delta_ws, hipStream_t st);
