@@ -81,7 +81,24 @@ def stage_times(nv, meta, Q, Kc, K, V, S, iters):
     t_sel = time_events(lambda: nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S), iters)
     t_att = time_events(lambda: nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched"), iters)
     L = (ranges[..., 1] - ranges[..., 0]).clamp_min(0).sum(-1).double()
-    return t_sc, t_sel, t_att, float(L.sum().item()), float(L.mean().item())
+    return t_sc, t_sel, t_att, float(L.sum().item()), float(L.mean().item()), gathered_tiles(ranges, K.shape[2], max(1, 16 // H))
+
+
+def gathered_tiles(ranges, S_kv, tpw):
+    """32-key K/V tiles the query-tile kernel really brings into LDS: the union over the tpw rows one wave owns (sel_attn_rows_mfma.hip)"""
+    Bq, Sq, Gq = ranges.shape[:3]
+    nt = (S_kv + 31) // 32
+    s, e = ranges[..., 0].long().clamp(0, S_kv), ranges[..., 1].long().clamp(0, S_kv)
+    live = (e > s).to(torch.int32)
+    diff = torch.zeros(Bq, Sq, Gq, nt + 1, dtype=torch.int32, device=ranges.device)
+    diff.scatter_add_(3, (s >> 5).clamp(max=nt), live)
+    diff.scatter_add_(3, (((e - 1).clamp_min(0) >> 5) + 1).clamp(max=nt), -live)
+    cover = diff.cumsum(3)[..., :nt] > 0
+    Sp = Sq // tpw * tpw
+    n = cover[:, :Sp].reshape(Bq, Sp // tpw, tpw, Gq, nt).any(2).sum()
+    if Sp < Sq:
+        n = n + cover[:, Sp:].any(1).sum()
+    return float(n.item())
 
 
 def decode_bench(nv, B, S_ctx, steps, device):
@@ -475,17 +492,20 @@ def main():
                    "global_batch": world * B, "seq_len": S, "parallelism": f"batch x group shard over {world} GPU(s), no collective"},
     }
     if rank == 0:
-        t_sc, t_sel, t_att, Lsum, Lmean = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
+        t_sc, t_sel, t_att, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
+        gathered = n_tiles * 32 * (D + D) * 2
         alg_bytes = Lsum * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V counted once per group
         achieved = alg_bytes / (t_att * 1e-3) / 1e9
         flops = 4.0 * H * Lsum * D
-        out["roofline"] = {"kernel": "sel_attn_fwd_mfma_kernel<bf16,64>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        out["roofline"] = {"kernel": "sel_attn_rows_mfma_kernel<bf16,64,1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(S, B),
                            "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01/traffic_*.json); the gather is "
                                            "L2 / Infinity-Cache resident, so achieved (algorithmic) exceeds what reaches HBM",
-                           "l2_peak": L2_PEAK_GBPS, "l2_frac": achieved / L2_PEAK_GBPS,
+                           "l2_peak": L2_PEAK_GBPS, "gathered_bytes_per_launch": gathered,
+                           "l2_frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS,
                            "l2_note": "the XCD-aware (b,g)-major order keeps one pair's K/V (1 MiB at S=4096) in its XCD's 4 MiB L2: the gather "
-                                      "runs against the aggregate L2 bandwidth, not HBM",
+                                      "runs against the aggregate L2 bandwidth, not HBM.  gathered = the 32-key tiles really brought into LDS "
+                                      "(two rows of one wave share a tile both selected), algorithmic = the per-row figure of SURVEY 8(d)",
                            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
                            "mfma_tflops": flops / (t_att * 1e-3) / 1e12, "mfma_frac": flops / (t_att * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         out["stages_ms"] = {"scores": t_sc, "select_and_attention_one_launch": t_att, "select_standalone_kernel": t_sel}
@@ -498,7 +518,7 @@ def main():
                 for S2, B2 in ((4096, 1), (16384, 1), (65536, 1)):
                     m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
                     ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 3, warm=1)
-                    sc, se, at, Ls, Lm = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 3)
+                    sc, se, at, Ls, Lm, _ = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 3)
                     extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "scores_ms": sc, "select_standalone_ms": se, "select_and_attention_ms": at,
                                                     "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9, "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12}
                     del m2, Q2, Kc2, K2, V2

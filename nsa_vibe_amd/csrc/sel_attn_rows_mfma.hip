@@ -1,4 +1,4 @@
-// Query-tile form of the MFMA selection attention (prefill / training forward; bf16 / f16, Dk = Dv = 64, 3 <= h <= 16).
+// Query-tile form of the MFMA selection attention (prefill / training forward; bf16 / f16, Dk = Dv in {64, 128}, h <= 8 for row sharing).
 //
 // sel_attn_mfma.hip gives every query row its own wave: the h heads of the row fill h of the 16 MFMA columns and every
 // selected K/V tile is fetched once PER ROW.  Neighbouring rows of one (b,g) select largely the same blocks (block 0, the
@@ -452,13 +452,13 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
 //   NT = 3: 48/h rows; pays off only while (nearly) every row selects (nearly) every tile, i.e. short contexts (S_kv <= ~n*l').
 int sel_attn_rows_tpw(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int *nt) {
     *nt = 1;
-    if (!(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) || Dk != 64 || Dv != 64 || h < 1 || h > 16) return 0;
+    if (!(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) || Dk != Dv || (Dk != 64 && Dk != 128) || h < 1 || h > 16) return 0;
     if (n < 1 || n > 64 || S_kv < 1 || S_kv > 131072) return 0;
     int mode = -1;  // NSA_HIP_SEL_ROWS: 0 = off, 1 = pairs (NT 1), 3 = query tiles (NT 3); unset = automatic
     if (const char *e = getenv("NSA_HIP_SEL_ROWS")) mode = atoi(e);
     if (mode == 0) return 0;
     int want_nt = 1;
-    if (mode == 3 || (mode < 0 && S_kv <= 1536 && R >= 16384 && h >= 3)) want_nt = 3;
+    if (Dk == 64 && (mode == 3 || (mode < 0 && S_kv <= 1536 && R >= 16384 && h >= 3))) want_nt = 3;
     if (want_nt == 3 && h < 3) want_nt = 1;
     const int tpw = (16 * want_nt) / h;
     if (tpw < 2 || S < 2 * tpw) return 0;
@@ -466,7 +466,7 @@ int sel_attn_rows_tpw(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, 
     return tpw;
 }
 
-template <typename T, int NT>
+template <typename T, int D, int NT>
 static int launch_rows_t(const SelAttnParams &P0, int tpw, hipStream_t st) {
     SelAttnParams P = P0;
     P.tpw = tpw;
@@ -475,7 +475,7 @@ static int launch_rows_t(const SelAttnParams &P0, int tpw, hipStream_t st) {
     P.part = nullptr;
     const int rg_ints = (2 * tpw * P.n + 3) & ~3;
     const int bm_ints = (2 * tpw * P.nw + 16 + 3) & ~3;
-    P.wave_lds = 2 * Geo<64>::TILE_BYTES + 4 * (rg_ints + bm_ints);
+    P.wave_lds = 2 * Geo<D>::TILE_BYTES + 4 * (rg_ints + bm_ints);
     const size_t lds = 4 * (size_t)P.wave_lds;
     NSA_CHECK_ARG(lds <= 160 * 1024, "sel_attn_rows: %zu B of LDS needed", lds);
     const int64_t nbg = P.R / P.S;
@@ -492,7 +492,7 @@ static int launch_rows_t(const SelAttnParams &P0, int tpw, hipStream_t st) {
         NSA_CHECK_ARG(c <= 16 && SP.W <= 64 && SP.W == P.n, "fused selection: S_sel <= 1024 and at most 64 ranges per row");
         cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
     }
-    void (*k)(SelAttnParams, SelectParams, int) = sel_attn_rows_mfma_kernel<T, 64, NT>;
+    void (*k)(SelAttnParams, SelectParams, int) = sel_attn_rows_mfma_kernel<T, D, NT>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_rows_mfma");
@@ -500,8 +500,9 @@ static int launch_rows_t(const SelAttnParams &P0, int tpw, hipStream_t st) {
 }
 
 int launch_sel_attn_rows_mfma(const SelAttnParams &P, int dtype, int tpw, int nt, hipStream_t st) {
-    if (nt == 3) return dtype == NSA_DT_BF16 ? launch_rows_t<__bf16, 3>(P, tpw, st) : launch_rows_t<_Float16, 3>(P, tpw, st);
-    return dtype == NSA_DT_BF16 ? launch_rows_t<__bf16, 1>(P, tpw, st) : launch_rows_t<_Float16, 1>(P, tpw, st);
+    if (P.Dk == 128) return dtype == NSA_DT_BF16 ? launch_rows_t<__bf16, 128, 1>(P, tpw, st) : launch_rows_t<_Float16, 128, 1>(P, tpw, st);
+    if (nt == 3) return dtype == NSA_DT_BF16 ? launch_rows_t<__bf16, 64, 3>(P, tpw, st) : launch_rows_t<_Float16, 64, 3>(P, tpw, st);
+    return dtype == NSA_DT_BF16 ? launch_rows_t<__bf16, 64, 1>(P, tpw, st) : launch_rows_t<_Float16, 64, 1>(P, tpw, st);
 }
 
 }  // namespace nsa

@@ -354,3 +354,67 @@ def test_first_key_parity_mode_matches_reference_default_executors(nv, orc, name
     wild = torch.tensor([[-5, -1], [S_kv - 2, S_kv + 100]], dtype=torch.int32, device="cuda").expand(*rg.shape[:3], 2, 2).contiguous()
     out = nv.selection_attention_first_key_parity(Q, K, V, wild)
     assert torch.equal(out, V[:, :, S_kv - 2][:, None, :, None, :].expand_as(out))
+
+
+# ---- the query-tile forward kernel (sel_attn_rows_mfma.hip): several rows per wave sharing K/V tiles -------------------------
+@pytest.mark.parametrize("mode", ["1", "3"])  # 1 = 16/h rows per wave ("pairs" at h = 6), 3 = 48/h rows
+@pytest.mark.parametrize("h,D", [(3, 64), (4, 64), (5, 64), (6, 64), (8, 64), (16, 64), (2, 128), (4, 128), (8, 128)])
+def test_query_tile_kernel_against_oracle(nv, orc, mode, h, D, monkeypatch):
+    """rows of one wave with DIFFERENT selections: unaligned, overlapping and duplicate ranges (partially covered tiles), an empty
+    row, a row covering everything, a key range that ends in the last (partial) tile of K/V, odd S (last wave short)"""
+    monkeypatch.setenv("NSA_HIP_SEL_ROWS", mode)
+    rng = np.random.default_rng([h, D, int(mode)])
+    B, S, G, n, S_kv = 2, 37, 2, 9, 333  # S_kv not a multiple of 32
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv)
+    rg[0, 0, 0] = 0  # empty row
+    rg[0, 1, 0] = 0
+    rg[0, 1, 0, 0] = (0, S_kv)  # everything
+    rg[0, 2, 0, :3] = [(10, 50), (40, 70), (40, 70)]  # overlap + duplicate
+    rg[0, 3, 0, :2] = [(320, 400), (-7, 3)]  # clamped on both ends, ends in the partial last tile
+    rg[1, 5, 1] = 0
+    rg[1, 5, 1, 0] = (95, 97)  # two keys straddling nothing: one partially covered tile only
+    for dtype in (torch.bfloat16, torch.float16):
+        run_case(nv, orc, Q, K, V, rg, dtype, variant=2)
+
+
+def test_query_tile_kernel_long_context_second_bitmap_word_group(nv, monkeypatch):
+    """S_kv > 65536: the tile schedule spans more than 64 bitmap words (second register of the schedule); against the generic kernel"""
+    rng = np.random.default_rng(123)
+    B, S, G, h, D, n, S_kv = 1, 24, 2, 6, 64, 16, 100000
+    Q = torch.from_numpy(rng.standard_normal((B, S, G, h, D), dtype=np.float32)).cuda().bfloat16()
+    K = torch.from_numpy(rng.standard_normal((B, G, S_kv, D), dtype=np.float32)).cuda().bfloat16()
+    V = torch.from_numpy(rng.standard_normal((B, G, S_kv, D), dtype=np.float32)).cuda().bfloat16()
+    st = rng.integers(0, S_kv // 64, size=(B, S, G, n)) * 64
+    rg = np.stack([st, np.minimum(st + 64, S_kv)], axis=-1).astype(np.int32)
+    rg[0, :, :, 0] = (0, 64)
+    rg[0, :, :, 1] = (S_kv - 100, S_kv)  # the very end, unaligned
+    rg[0, 3, 1, 2] = (65500, 65600)  # straddles the word-group boundary (tile 2047 | 2048)
+    want = nv.selection_attention_hip(Q, K, V, dev(rg), variant=1).float()
+    for mode in ("1", "3"):
+        monkeypatch.setenv("NSA_HIP_SEL_ROWS", mode)
+        got = nv.selection_attention_hip(Q, K, V, dev(rg), variant=2, return_lse=True)
+        assert (got[0].float() - want).abs().max().item() <= 1e-2
+        assert torch.isfinite(got[1]).all()
+
+
+@pytest.mark.parametrize("mode", ["sequential", "batched"])
+def test_query_tile_kernel_equals_one_row_kernel_on_selector_output(nv, mode, monkeypatch):
+    """m7c geometry, ranges from the real selector (fused in the launch): all three forward kernels agree, and the fused launch
+    writes the same ranges whichever kernel hosts the selector"""
+    torch.manual_seed(3)
+    B, S, G, h, D = 2, 1500, 2, 6, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    p = torch.rand(B, S, G, meta.S_sel, device="cuda")
+    outs = {}
+    for m in ("0", "1", "3"):
+        monkeypatch.setenv("NSA_HIP_SEL_ROWS", m)
+        outs[m] = nv.select_and_attend(p, Q, K, V, meta, 16, mode=mode, scale=0.125)
+    for m in ("1", "3"):
+        assert torch.equal(outs[m][0], outs["0"][0])
+        assert (outs[m][1].float() - outs["0"][1].float()).abs().max().item() <= 2e-2
