@@ -270,6 +270,282 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(SelAttnBwdParams P, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------ 2b. dQ, several rows per wave
+// Query-tile form of the dQ kernel (see sel_attn_rows_mfma.hip): one wave owns TPW = 16/h consecutive rows of one (b,g) (h = 6: two
+// rows = 12 of the 16 MFMA columns) and walks the UNION of their selected 32-key tiles, so the three LDS images of a tile (K rows,
+// K transposable, V rows: 12 KB written and read back) are built once for the rows that share it.  Tile schedule and ownership
+// come from per-row tile bitmaps (`touch` / `full`, LDS atomics); a slot whose row did not select a key gets p = 0.
+__device__ __forceinline__ unsigned bwd_bit_span(int lo, int hi) {  // bits lo..hi inclusive
+    const unsigned up = hi >= 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u);
+    return up & ~((1u << lo) - 1u);
+}
+__device__ __forceinline__ void bwd_lds_or(unsigned *p, unsigned v) {
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    __hip_atomic_fetch_or((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bwd_dq_rows_kernel(SelAttnBwdParams P, const float *__restrict__ delta, int map_mode, int tpw, int NW,
+                                                          int wave_lds) {
+    using M = BwdT<T>;
+    using x8 = typename M::x8;
+    using x4 = typename M::x4;
+    constexpr int TILE = 32 * BROWB;  // 4 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int h = P.h, n = P.n;
+    const int ngrp = (P.S + tpw - 1) / tpw;
+    const int nbg = (int)(P.R / P.S);
+    const int W4 = (ngrp + 3) >> 2;
+    int bg, tc;
+    if (map_mode == 2) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bg = (idx / W4) * 8 + xcd;
+        tc = idx % W4;
+    } else {
+        bg = blockIdx.x / W4;
+        tc = blockIdx.x % W4;
+    }
+    const int grp = 4 * tc + wave;
+    if (grp >= ngrp || bg >= nbg) return;
+    const int b = bg / P.G, g = bg - b * P.G;
+    const int tw0 = grp * tpw, ntok = min(tpw, P.S - tw0);
+
+    unsigned char *k_row = smem + (size_t)wave * wave_lds;  // K, row image
+    unsigned char *k_tr = k_row + TILE;                     // K, transposable image
+    unsigned char *v_row = k_tr + TILE;                     // V, row image
+    int *rg = (int *)(v_row + TILE);                        // [tpw][n][2]
+    unsigned *fullw = (unsigned *)(rg + ((2 * tpw * n + 3) & ~3));
+    unsigned *touchw = fullw + tpw * NW;
+    unsigned *kmask = touchw + tpw * NW;  // [16]
+
+    for (int i = lane; i < 2 * tpw * NW + 16; i += 64) fullw[i] = 0u;
+    for (int r = 0; r < ntok; ++r) {
+        const int64_t row = ((int64_t)b * P.S + tw0 + r) * P.G + g;
+        if (lane < n) {
+            const int32_t *in = P.ranges + (row * n + lane) * 2;
+            const int s = min(max(in[0], 0), P.S_kv);
+            const int e = min(max(in[1], s), P.S_kv);
+            rg[2 * (r * n + lane)] = s;
+            rg[2 * (r * n + lane) + 1] = e;
+        }
+    }
+    wave_lds_fence();
+    for (int p = lane; p < ntok * n; p += 64) {
+        const int r = p / n;
+        const int s = rg[2 * p], e = rg[2 * p + 1];
+        if (e > s) {
+            const int ta = s >> 5, tb = (e - 1) >> 5;
+            const int fa = (s + 31) >> 5, fb = (e >> 5) - 1;
+            for (int w = ta >> 5; w <= (tb >> 5); ++w) {
+                const int base = 32 * w;
+                bwd_lds_or(&touchw[r * NW + w], bwd_bit_span(max(ta, base) - base, min(tb, base + 31) - base));
+                const int flo = max(fa, base), fhi = min(fb, base + 31);
+                if (flo <= fhi) bwd_lds_or(&fullw[r * NW + w], bwd_bit_span(flo - base, fhi - base));
+            }
+        }
+    }
+    wave_lds_fence();
+    unsigned u0 = 0u, u1 = 0u;
+    for (int r = 0; r < ntok; ++r) {
+        if (lane < NW) u0 |= touchw[r * NW + lane];
+        if (lane + 64 < NW) u1 |= touchw[r * NW + 64 + lane];
+    }
+    unsigned long long nz0 = __ballot(u0 != 0u), nz1 = __ballot(u1 != 0u);
+
+    const int rho = lane & 15, q = lane >> 4;
+    const int tok = rho / h, head = rho - tok * h;
+    const bool used = tok < ntok;
+    const int64_t orow = used ? ((((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head) : -1;  // row * h + head
+
+    x8 qf[2], dof[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+        if (used) {
+            a = *(const u32x4 *)((const T *)P.Q + orow * BD + 32 * s + 8 * q);
+            c = *(const u32x4 *)((const T *)P.dO + orow * BD + 32 * s + 8 * q);
+        }
+        qf[s] = __builtin_bit_cast(x8, a);
+        dof[s] = __builtin_bit_cast(x8, c);
+    }
+    float lse2 = 0.f, dlt = 0.f;
+    bool live = false;  // rows without any selected key have lse = -inf: every p is 0
+    if (used) {
+        const float l = P.lse[orow];
+        live = l > -INFINITY;
+        lse2 = live ? l * LOG2E : 0.f;
+        dlt = delta[orow];
+    }
+    const float c2 = P.scale * LOG2E;
+
+    const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
+    const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
+    const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;
+    const int ld_row = lane >> 3, ld_piece = lane & 7;
+    uint32_t kd_row[4], kd_tr[4], vd_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + ld_row;
+        kd_row[i] = (uint32_t)(ld_row * krowb + ((ld_piece ^ bswz_row(r)) << 4));
+        kd_tr[i] = (uint32_t)(ld_row * krowb + (((((ld_piece >> 1) ^ bswz_tr(r)) << 1) | (ld_piece & 1)) << 4));
+        vd_row[i] = (uint32_t)(ld_row * vrowb + ((ld_piece ^ bswz_row(r)) << 4));
+    }
+    uint32_t rd_row[2], rd_tr[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rd_row[s] = off_row_img(rho, 4 * s + q);
+    {
+        const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) rd_tr[m] = r * BROWB + ((m ^ bswz_tr(r)) << 5) + 8 * pp;
+    }
+    auto make_rsrc = [&](const unsigned char *base, int64_t bytes) {
+        const uint64_t a = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    [[maybe_unused]] const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + BROWB);
+    [[maybe_unused]] const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + BROWB);
+    [[maybe_unused]] const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    [[maybe_unused]] const int kstep = uniform(8 * (int)krowb), vstep = uniform(8 * (int)vrowb);
+    auto issue_dma = [&](int tok0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);
+        const bool whole = tok0 + 32 <= P.S_kv;
+        const int last = P.S_kv - 1 - tok0;  // rows past the end of K/V re-read the last row (masked: such a tile is never `full`)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rowshift = whole ? 0 : (min(8 * i + ld_row, last) - ld_row);
+            const int kso = whole ? ks + i * kstep : ks, vso = whole ? vs + i * vstep : vs;
+            const uint32_t kadd = whole ? 0u : (uint32_t)(rowshift * krowb32), vadd = whole ? 0u : (uint32_t)(rowshift * vrowb32);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(k_row + i * 1024), 16, kd_row[i] + kadd, kso, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(k_tr + i * 1024), 16, kd_tr[i] + kadd, kso, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(v_row + i * 1024), 16, vd_row[i] + vadd, vso, 0, 0);
+        }
+#else
+        (void)tok0;
+#endif
+    };
+
+    int iw = 0;
+    unsigned ibits = 0u;
+    auto next_tile = [&]() -> int {
+        if (ibits == 0u) {
+            if (nz0) {
+                iw = __builtin_ctzll(nz0);
+                nz0 &= nz0 - 1ull;
+                ibits = (unsigned)__builtin_amdgcn_readlane((int)u0, iw);
+            } else if (nz1) {
+                const int w = __builtin_ctzll(nz1);
+                nz1 &= nz1 - 1ull;
+                ibits = (unsigned)__builtin_amdgcn_readlane((int)u1, w);
+                iw = 64 + w;
+            } else {
+                return -1;
+            }
+        }
+        const int bit = __builtin_ctz(ibits);
+        ibits &= ibits - 1u;
+        return 32 * iw + bit;
+    };
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dq[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cur = next_tile();
+    if (cur >= 0) issue_dma(32 * cur);
+    while (cur >= 0) {
+        const int nxt = next_tile();
+        const int tok0 = 32 * cur;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        x8 kfr[2][2], vfr[2][2];
+        x4 ktr[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kfr[u][s] = *(const x8 *)(k_row + rd_row[s] + u * 16 * BROWB);
+                vfr[u][s] = *(const x8 *)(v_row + rd_row[s] + u * 16 * BROWB);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ktr[u][m] = tr_read<x4>(k_tr + rd_tr[m] + u * 16 * BROWB);
+        unsigned fw = 0u, tw = 0u;
+        if (lane < ntok) {
+            fw = fullw[lane * NW + (cur >> 5)];
+            tw = touchw[lane * NW + (cur >> 5)];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt >= 0) issue_dma(32 * nxt);
+        const unsigned fullm = (unsigned)__ballot((fw >> (cur & 31)) & 1u);
+        const unsigned touchm = (unsigned)__ballot((tw >> (cur & 31)) & 1u);
+        const unsigned partm = touchm & ~fullm;
+        if (partm) {  // partially covered by some row: that row's 32-key mask from its ranges
+            if (lane < 16) kmask[lane] = 0u;
+            wave_lds_fence();
+            for (int p = lane; p < ntok * n; p += 64) {
+                const int r = p / n;
+                const int lo = max(rg[2 * p], tok0) - tok0, hi = min(rg[2 * p + 1], tok0 + 32) - tok0;
+                if (((partm >> r) & 1u) && hi > lo) bwd_lds_or(&kmask[r], bwd_bit_span(lo, hi - 1));
+            }
+            wave_lds_fence();
+        }
+        unsigned km = 0u;
+        if (live) {
+            if ((fullm >> tok) & 1u) km = 0xffffffffu;
+            else if ((partm >> tok) & 1u) km = kmask[tok];
+        }
+        km >>= 4 * q;  // bit 16u + j = key 16u + 4q + j of the tile
+
+        f32x4 sacc[2], pacc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            sacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sacc[u] = M::mma32(kfr[u][s], qf[s], sacc[u]);
+                pacc[u] = M::mma32(vfr[u][s], dof[s], pacc[u]);
+            }
+        }
+        x8 dsf;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][j], c2, -lse2));
+                if (!((km >> (16 * u + j)) & 1u)) p = 0.f;
+                dsf[4 * u + j] = Elt<T>::from_f(p * (pacc[u][j] - dlt) * P.scale);
+            }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            x8 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = ktr[0][m][j];
+                a[4 + j] = ktr[1][m][j];
+            }
+            dq[m] = M::mma32(a, dsf, dq[m]);
+        }
+        cur = nxt;
+    }
+    if (used) {
+        T *dQr = (T *)P.dQ + orow * BD;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = Elt<T>::from_f(dq[m][j]);
+            *(x4 *)(dQr + 16 * m + 4 * q) = ov;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 3. dK / dV (key-block-major)
 constexpr int KB_NCT = 8;
 #ifdef NSA_DBG_WGTIME
@@ -609,8 +885,25 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
     }
     constexpr size_t lds = 4 * (3 * 32 * BROWB + ((SEG_INTS * 4 + 15) / 16) * 16);
     if (!P.skip_delta_dq) {
-        hipLaunchKernelGGL(bwd_dq_kernel<T>, dim3(grid), dim3(256), lds, st, P, (const float *)delta, map_mode);
-        NSA_LAUNCH_CHECK("bwd_dq");
+        // rows of one wave share the K/V tile images when 16/h >= 2 rows fit the MFMA columns (NSA_HIP_SEL_ROWS=0: one row per wave)
+        int tpw = 16 / P.h;
+        if (const char *e = getenv("NSA_HIP_SEL_ROWS"))
+            if (atoi(e) == 0) tpw = 1;
+        const int nw = ((P.S_kv + 31) / 32 + 31) / 32;
+        if (tpw >= 2 && P.S >= 2 * tpw && P.n >= 1 && P.n <= 64 && nw <= 128) {
+            const int rg_ints = (2 * tpw * P.n + 3) & ~3, bm_ints = (2 * tpw * nw + 16 + 3) & ~3;
+            const int wave_lds = 3 * 32 * BROWB + 4 * (rg_ints + bm_ints);
+            const int64_t nbg2 = P.R / P.S, ngrp = (P.S + tpw - 1) / tpw, W4 = (ngrp + 3) / 4;
+            NSA_CHECK_ARG(nbg2 * W4 < ((int64_t)1 << 31) && 4 * (size_t)wave_lds <= 160 * 1024, "bwd_dq_rows: launch too large");
+            if (4 * (size_t)wave_lds > 64 * 1024)
+                NSA_HIP_TRY(hipFuncSetAttribute((const void *)bwd_dq_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * wave_lds));
+            hipLaunchKernelGGL(bwd_dq_rows_kernel<T>, dim3((unsigned)(nbg2 * W4)), dim3(256), 4 * (size_t)wave_lds, st, P, (const float *)delta,
+                               (nbg2 % 8 == 0) ? 2 : 1, tpw, nw, wave_lds);
+            NSA_LAUNCH_CHECK("bwd_dq_rows");
+        } else {
+            hipLaunchKernelGGL(bwd_dq_kernel<T>, dim3(grid), dim3(256), lds, st, P, (const float *)delta, map_mode);
+            NSA_LAUNCH_CHECK("bwd_dq");
+        }
     }
     const int64_t nbg = (int64_t)(P.R / P.S);
     NSA_CHECK_ARG(nbg <= 65535, "bwd: B*G too large for one launch");
