@@ -418,3 +418,29 @@ def test_query_tile_kernel_equals_one_row_kernel_on_selector_output(nv, mode, mo
     for m in ("1", "3"):
         assert torch.equal(outs[m][0], outs["0"][0])
         assert (outs[m][1].float() - outs["0"][1].float()).abs().max().item() <= 2e-2
+
+
+def test_backward_query_tile_dq_long_context_and_kernel_switch(nv, monkeypatch):
+    """dQ of the query-tile kernel (rows of a wave share tile images) == dQ of the one-row kernel on the same inputs, including a
+    context of more than 65536 keys (second schedule register) and rows with different, unaligned, overlapping ranges"""
+    rng = np.random.default_rng(2024)
+    B, S, G, h, D, n, S_kv = 1, 21, 2, 6, 64, 8, 70000
+    Q = dev(rng.standard_normal((B, S, G, h, D), dtype=np.float32), torch.bfloat16)
+    K = dev(rng.standard_normal((B, G, S_kv, D), dtype=np.float32), torch.bfloat16)
+    V = dev(rng.standard_normal((B, G, S_kv, D), dtype=np.float32), torch.bfloat16)
+    dO = dev(rng.standard_normal((B, S, G, h, D), dtype=np.float32), torch.bfloat16)
+    st = rng.integers(0, S_kv - 200, size=(B, S, G, n))
+    rg = np.stack([st, st + rng.integers(0, 150, size=st.shape)], axis=-1).astype(np.int32)
+    rg[0, :, :, 0] = (0, 64)
+    rg[0, :, :, 1] = (65500, 65610)  # straddles tile 2047 | 2048
+    rg[0, 2, 0] = 0  # empty row
+    rg[0, 5, 1, 2] = (69990, 70000)  # the partial last tile
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NSA_HIP_SEL_ROWS", mode)
+        q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+        nv.selection_attention_hip(q, k, v, dev(rg), variant=2).backward(dO)
+        res[mode] = (q.grad, k.grad, v.grad)
+    for a, b_ in zip(res["0"], res["1"]):
+        assert torch.isfinite(a).all() and (a.float() - b_.float()).abs().max().item() <= 2e-2 * max(1.0, a.float().abs().max().item())
+    assert not res["1"][0][0, 2, 0].any()  # empty row: zero gradient
