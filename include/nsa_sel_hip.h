@@ -167,8 +167,13 @@ typedef struct nsa_kv_desc {
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T) for few rows (decode projections).  epilogue 0: none, 1: silu, 2: + residual[M,N]. */
 NSA_API int nsa_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epilogue, const void *residual,
                      void *stream);
-/* y[M,dim] = RMSNorm(x) * w for few rows (llama_block_nsa.py:10-19). */
+/* y[M,dim] = RMSNorm(x) * w, one wave per row, rounded where the reference's eager chain rounds (llama_block_nsa.py:10-19). */
 NSA_API int nsa_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, void *stream);
+/* Backward of nsa_rmsnorm_rows (training): dx[M,dim] and dw[dim] (activation dtype) from x, w, dy.  dim % 8 == 0, dim <= 4096, 16-byte
+ * aligned tensors; dw is a fixed-order sum over workgroup partials (no atomics).  workspace: nsa_rmsnorm_rows_bwd_workspace bytes. */
+NSA_API size_t nsa_rmsnorm_rows_bwd_workspace(int M, int dim);
+NSA_API int nsa_rmsnorm_rows_bwd(const void *x, const void *w, const void *dy, void *dx, void *dw, int M, int dim, float eps, int dtype,
+                         void *workspace, size_t workspace_bytes, void *stream);
 /* RoPE (Q over the flattened head axis, K_sel/K_win per group; nsa_attention.py:552-572, 1002-1024) on a fused projection
  * proj [B,S,NQ+3GDk+3GDv] and append of the S tokens at cache position t0: Q_out [B,S,G,h,Dk]. */
 NSA_API int nsa_rope_cache_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, void *Q_out, int S, int t0,

@@ -55,6 +55,8 @@ SIGNATURES = {
     "nsa_band_attn_fwd": (_i, [_vp] * 5 + [_i] * 7 + [_i64] * 6 + [_i] * 5 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_linear_small": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "nsa_rmsnorm_rows": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "nsa_rmsnorm_rows_bwd_workspace": (_sz, [_i, _i]),
+    "nsa_rmsnorm_rows_bwd": (_i, [_vp] * 5 + [_i, _i, _f, _i, _vp, _sz, _vp]),
     "nsa_model_decode_step_workspace": (_sz, [_pb, _i, _i, _i]),
     "nsa_model_decode_step": (_i, [_pb, _pk, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "nsa_block_decode_step_workspace": (_sz, [_pb, _i, _i]),

@@ -603,12 +603,39 @@ int launch_cmp_pool_bwd(const CmpPoolParams &P, const void *dKc, const void *dVc
 // ------------------------------------------------------------------------------------------ RMSNorm of a few rows
 // y = (x * rsqrt(mean(x^2) + eps)) * w, one wave per row, rounded where the eager chain rounds (llama_block_nsa.py:16-19)
 template <typename T>
+__device__ __forceinline__ void store8(T *p, const float (&v)[8]) {  // 8 consecutive elements, 16-byte aligned for 2-byte types
+    if constexpr (sizeof(T) == 2) {
+        u32x4 raw;
+        T *e = (T *)&raw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = Elt<T>::from_f(v[j]);
+        *(u32x4 *)p = raw;
+    } else {
+        *(f32x4 *)p = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4 *)(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T *__restrict__ x, const T *__restrict__ w, T *__restrict__ y, int M, int dim,
-                                                           float eps) {
+                                                           float eps, int vec) {
     const int lane = lane_id();
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const T *xr = x + (int64_t)m * dim;
+    T *yr = y + (int64_t)m * dim;
+    if (vec) {  // dim % 8 == 0 and 16-byte aligned rows: whole rows per load instruction
+        const float r = row_rms<T>(xr, dim, true, eps);
+        for (int k = lane * 8; k < dim; k += 512) {
+            float xv[8], wv[8], o[8];
+            load8<T>(xr + k, 8, true, xv);
+            load8<T>(w + k, 8, true, wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rnd<T>(xv[j] * r) * wv[j];
+            store8<T>(yr + k, o);
+        }
+        return;
+    }
     float acc = 0.f;
     for (int i = lane; i < dim; i += 64) {
         const float v = Elt<T>::to_f(xr[i]);
@@ -617,18 +644,122 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T *__restrict__
     float r = rnd<T>(wave_sum(acc) / (float)dim);
     r = rnd<T>(r + eps);
     r = rnd<T>(1.0f / sqrtf(r));
-    T *yr = y + (int64_t)m * dim;
     for (int i = lane; i < dim; i += 64) yr[i] = Elt<T>::from_f(rnd<T>(Elt<T>::to_f(xr[i]) * r) * Elt<T>::to_f(w[i]));
 }
 
 int launch_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, hipStream_t st) {
     if (M == 0) return NSA_OK;
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
-    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rmsnorm_rows_kernel<float>, grid, block, 0, st, (const float *)x, (const float *)w, (float *)y, M, dim, eps);
-    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rmsnorm_rows_kernel<__bf16>, grid, block, 0, st, (const __bf16 *)x, (const __bf16 *)w, (__bf16 *)y, M, dim, eps);
-    else hipLaunchKernelGGL(rmsnorm_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16 *)x, (const _Float16 *)w, (_Float16 *)y, M, dim, eps);
+    const int vec = dim % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0;
+    if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rmsnorm_rows_kernel<float>, grid, block, 0, st, (const float *)x, (const float *)w, (float *)y, M, dim, eps, vec);
+    else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rmsnorm_rows_kernel<__bf16>, grid, block, 0, st, (const __bf16 *)x, (const __bf16 *)w, (__bf16 *)y, M, dim, eps, vec);
+    else hipLaunchKernelGGL(rmsnorm_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16 *)x, (const _Float16 *)w, (_Float16 *)y, M, dim, eps, vec);
     NSA_LAUNCH_CHECK("rmsnorm_rows");
     return NSA_OK;
+}
+
+// backward of y = (x r) w, r = rsqrt(mean(x^2) + eps):  dx = r (g - xh mean(g xh)),  g = dy w,  xh = x r;  dw = sum_rows dy xh.
+// A workgroup owns RMS_BWD_ROWS consecutive rows (one wave per row at a time); the per-column dw sums stay in registers across the
+// rows of a wave, are added over the 4 waves through LDS and leave as one fp32 partial row per workgroup; a second kernel adds the
+// partial rows in fixed order (no atomics: reproducible).  dim % 8 == 0, dim <= 4096.
+constexpr int RMS_BWD_ROWS = 32;
+constexpr int RMS_BWD_CH = 8;  // 8-element chunks per lane: dim <= 512 * 8
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_rows_bwd_kernel(const T *__restrict__ x, const T *__restrict__ w, const T *__restrict__ dy,
+                                                               T *__restrict__ dx, float *__restrict__ part, int M, int dim, float eps) {
+    __shared__ float red[4][64 * 8];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * RMS_BWD_ROWS;
+    float dwacc[RMS_BWD_CH][8];
+#pragma unroll
+    for (int c = 0; c < RMS_BWD_CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[c][j] = 0.f;
+    for (int m = r0 + wave; m < min(M, r0 + RMS_BWD_ROWS); m += 4) {
+        const T *xr = x + (int64_t)m * dim, *gr = dy + (int64_t)m * dim;
+        const float r = row_rms<T>(xr, dim, true, eps);
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < RMS_BWD_CH; ++c) {
+            const int k = lane * 8 + 512 * c;
+            if (k < dim) {
+                float xv[8], gv[8], wv[8];
+                load8<T>(xr + k, 8, true, xv);
+                load8<T>(gr + k, 8, true, gv);
+                load8<T>(w + k, 8, true, wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = xv[j] * r;
+                    dot = fmaf(gv[j] * wv[j], xh, dot);
+                    dwacc[c][j] = fmaf(gv[j], xh, dwacc[c][j]);
+                }
+            }
+        }
+        const float mean = wave_sum(dot) / (float)dim;
+        T *dr = dx + (int64_t)m * dim;
+#pragma unroll
+        for (int c = 0; c < RMS_BWD_CH; ++c) {
+            const int k = lane * 8 + 512 * c;
+            if (k < dim) {
+                float xv[8], gv[8], wv[8], o[8];
+                load8<T>(xr + k, 8, true, xv);
+                load8<T>(gr + k, 8, true, gv);
+                load8<T>(w + k, 8, true, wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = r * (gv[j] * wv[j] - xv[j] * r * mean);
+                store8<T>(dr + k, o);
+            }
+        }
+    }
+    // dw partial of the workgroup: waves added in fixed order
+#pragma unroll
+    for (int c = 0; c < RMS_BWD_CH; ++c) {
+        if (512 * c >= dim) break;  // uniform
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = dwacc[c][j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 512; i += 256) {
+            const int k = 512 * c + i;
+            if (k < dim) part[(int64_t)blockIdx.x * dim + k] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float *__restrict__ part, T *__restrict__ dw, int nparts, int dim) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= dim) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += part[(int64_t)p * dim + k];
+    dw[k] = Elt<T>::from_f(a);
+}
+
+size_t rmsnorm_rows_bwd_workspace(int M, int dim) { return (size_t)((M + RMS_BWD_ROWS - 1) / RMS_BWD_ROWS) * dim * sizeof(float); }
+
+template <typename T>
+static int launch_rmsnorm_bwd_t(const void *x, const void *w, const void *dy, void *dx, void *dw, int M, int dim, float eps, float *part,
+                                hipStream_t st) {
+    const int nparts = (M + RMS_BWD_ROWS - 1) / RMS_BWD_ROWS;
+    hipLaunchKernelGGL(rmsnorm_rows_bwd_kernel<T>, dim3((unsigned)nparts), dim3(256), 0, st, (const T *)x, (const T *)w, (const T *)dy, (T *)dx,
+                       part, M, dim, eps);
+    NSA_LAUNCH_CHECK("rmsnorm_rows_bwd");
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<T>, dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, st, (const float *)part, (T *)dw, nparts,
+                       dim);
+    NSA_LAUNCH_CHECK("rmsnorm_dw_reduce");
+    return NSA_OK;
+}
+
+int launch_rmsnorm_rows_bwd(const void *x, const void *w, const void *dy, void *dx, void *dw, int M, int dim, float eps, int dtype,
+                            void *workspace, size_t workspace_bytes, hipStream_t st) {
+    NSA_CHECK_ARG(dim % 8 == 0 && dim <= 512 * RMS_BWD_CH, "rmsnorm_rows_bwd: dim must be a multiple of 8 and <= %d (got %d)", 512 * RMS_BWD_CH, dim);
+    NSA_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0,
+                  "rmsnorm_rows_bwd: 16-byte aligned tensors required");
+    NSA_CHECK_ARG(workspace && workspace_bytes >= rmsnorm_rows_bwd_workspace(M, dim) && (uintptr_t)workspace % 16 == 0,
+                  "rmsnorm_rows_bwd: workspace too small");
+    if (dtype == NSA_DT_F32) return launch_rmsnorm_bwd_t<float>(x, w, dy, dx, dw, M, dim, eps, (float *)workspace, st);
+    if (dtype == NSA_DT_BF16) return launch_rmsnorm_bwd_t<__bf16>(x, w, dy, dx, dw, M, dim, eps, (float *)workspace, st);
+    return launch_rmsnorm_bwd_t<_Float16>(x, w, dy, dx, dw, M, dim, eps, (float *)workspace, st);
 }
 
 // ------------------------------------------------------------------------------------------ gate MLP + combine

@@ -53,6 +53,9 @@ int launch_embed_rows(const int32_t *tokens, const void *embed, void *x, int B, 
 size_t argmax_rows_workspace(int B, int vocab);
 int launch_argmax_rows(const void *logits, int32_t *next, int B, int vocab, int dtype, void *ws, hipStream_t st);
 int launch_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, float eps, int dtype, hipStream_t st);
+size_t rmsnorm_rows_bwd_workspace(int M, int dim);
+int launch_rmsnorm_rows_bwd(const void *x, const void *w, const void *dy, void *dx, void *dw, int M, int dim, float eps, int dtype,
+                            void *workspace, size_t workspace_bytes, hipStream_t st);
 int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t st);
 int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st);
 int launch_rope_cache_append_bwd(const RopeAppendParams &P, int dtype, hipStream_t st);

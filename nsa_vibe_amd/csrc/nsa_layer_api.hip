@@ -46,6 +46,16 @@ int nsa_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, floa
     return launch_rmsnorm_rows(x, w, y, M, dim, eps, dtype, (hipStream_t)stream);
 }
 
+size_t nsa_rmsnorm_rows_bwd_workspace(int M, int dim) { return M > 0 && dim > 0 ? rmsnorm_rows_bwd_workspace(M, dim) : 0; }
+
+int nsa_rmsnorm_rows_bwd(const void *x, const void *w, const void *dy, void *dx, void *dw, int M, int dim, float eps, int dtype,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(dt_ok(dtype), "rmsnorm_rows_bwd: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(M >= 1 && dim >= 1, "rmsnorm_rows_bwd: bad sizes");
+    NSA_CHECK_ARG(x && w && dy && dx && dw, "rmsnorm_rows_bwd: null pointer");
+    return launch_rmsnorm_rows_bwd(x, w, dy, dx, dw, M, dim, eps, dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int nsa_rope_cache_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void *proj, void *Q_out, int S, int t0,
                           void *stream) {
     if (int rc = check_layer(L, "rope_cache_append")) return rc;

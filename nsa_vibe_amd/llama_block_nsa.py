@@ -2,12 +2,13 @@
 
 Same module tree / parameter names as the reference (nsa/model/llama_block_nsa.py:10-106: norm1, attn, norm2, mlp.fc1,
 mlp.fc2; scripts/train_showcase.py:30-110 TinyLM: embed, blocks, norm_f, lm_head), so their checkpoints load unchanged.
-RMSNorm, the MLP, the embedding and the LM head are plain PyTorch-ROCm ops (hipBLASLt GEMMs): they are outside the hot
-path; the attention layer is the native one.  Beyond the reference's prefill-only `forward(x)`, the block and the model
+The MLP, the embedding and the LM head are plain PyTorch-ROCm ops (hipBLASLt GEMMs): they are outside the hot path; the
+attention layer and RMSNorm (one native kernel each way) are native.  Beyond the reference's prefill-only `forward(x)`, the block and the model
 carry a per-layer cache so that `decode(x_t, caches)` runs one token through all layers.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -22,6 +23,49 @@ from .nsa_attention import NSAAttention
 from .selection_scorer import _stream, workspace
 
 
+def _rmsnorm_native_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """GPU tensors of a kernel dtype, rows the vectorised kernels take (dim % 8 == 0, <= 4096); NSA_HIP_EAGER_TRAIN=1 keeps the eager chain"""
+    from .selection_scorer import _DT
+
+    return (x.is_cuda and x.dtype in _DT and w.dtype == x.dtype and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and x.numel() > 0
+            and os.getenv("NSA_HIP_EAGER_TRAIN", "0") != "1")
+
+
+class _RMSNormFn(torch.autograd.Function):
+    """RMSNorm rows through nsa_rmsnorm_rows / nsa_rmsnorm_rows_bwd (one kernel each way instead of the 6 + ~10 elementwise / reduction
+    kernels of the eager chain; the forward rounds where the chain rounds, so both routes give the same activations)"""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        from .selection_scorer import _DT
+
+        xc = x.contiguous()
+        wc = w.contiguous()
+        y = torch.empty_like(xc)
+        M, dim = xc.numel() // xc.shape[-1], xc.shape[-1]
+        rc = _lib.lib().nsa_rmsnorm_rows(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), M, dim, eps, _DT[xc.dtype], _stream(xc.device))
+        _lib.check(rc, "nsa_rmsnorm_rows")
+        ctx.save_for_backward(xc, wc)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .selection_scorer import _DT
+
+        xc, wc = ctx.saved_tensors
+        dyc = dy.contiguous()
+        M, dim = xc.numel() // xc.shape[-1], xc.shape[-1]
+        dx, dw = torch.empty_like(xc), torch.empty_like(wc)
+        L = _lib.lib()
+        ws = workspace(xc.device, L.nsa_rmsnorm_rows_bwd_workspace(M, dim) + 256, "rmsnorm_bwd")
+        wptr = (ws.data_ptr() + 255) & ~255
+        rc = L.nsa_rmsnorm_rows_bwd(xc.data_ptr(), wc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), dw.data_ptr(), M, dim, ctx.eps, _DT[xc.dtype],
+                                    wptr, ws.numel() - (wptr - ws.data_ptr()), _stream(xc.device))
+        _lib.check(rc, "nsa_rmsnorm_rows_bwd")
+        return dx, dw, None
+
+
 class RMSNorm(nn.Module):
     """x * rsqrt(mean(x^2) + eps) * weight (llama_block_nsa.py:10-19)"""
 
@@ -31,6 +75,8 @@ class RMSNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _rmsnorm_native_ok(x, self.weight):
+            return _RMSNormFn.apply(x, self.weight, float(self.eps))
         rms = x.pow(2).mean(dim=-1, keepdim=True).add(self.eps).rsqrt()
         return (x * rms) * self.weight
 

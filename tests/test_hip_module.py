@@ -539,3 +539,36 @@ def test_tiny_lm_training_steps_reduce_the_loss_like_the_eager_composition(monke
     for ls in losses.values():
         assert all(np.isfinite(ls)) and ls[-1] < ls[0] - 0.2
     assert abs(losses["native"][-1] - losses["eager"][-1]) < 0.15
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 50, 768), (1, 1, 64), (2, 33, 4096), (130, 256)])
+def test_rmsnorm_native_forward_backward_match_the_eager_chain(dtype, shape, monkeypatch):
+    """RMSNorm through nsa_rmsnorm_rows / nsa_rmsnorm_rows_bwd against the reference's eager chain (llama_block_nsa.py:10-19) under torch
+    autograd: same activations (the kernel rounds where the chain rounds), gradients within the dtype's rounding"""
+    from nsa_vibe_amd.llama_block_nsa import RMSNorm
+
+    torch.manual_seed(13)
+    norm = RMSNorm(shape[-1]).cuda().to(dtype)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(shape[-1], device="cuda") * 0.5 + 1.0)
+    x0 = torch.randn(*shape, device="cuda").to(dtype)
+    go = torch.randn(*shape, device="cuda").to(dtype)
+    res = {}
+    for mode in ("native", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        else:
+            monkeypatch.delenv("NSA_HIP_EAGER_TRAIN", raising=False)
+        norm.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = norm(x)
+        y.backward(go)
+        res[mode] = (y.detach().float(), x.grad.float(), norm.weight.grad.float())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, e, name in zip(res["native"], res["eager"], ("y", "dx", "dw")):
+        scale = max(1.0, e.abs().max().item())
+        bound = tol * scale * (4.0 if name == "dw" and dtype != torch.float32 else 1.0)  # eager dw sums bf16-rounded products
+        assert (a - e).abs().max().item() <= bound, (name, (a - e).abs().max().item(), scale)
+    if dtype == torch.bfloat16:
+        assert torch.equal(res["native"][0], res["eager"][0])
