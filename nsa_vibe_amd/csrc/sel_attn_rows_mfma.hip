@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
     // ---- per-slot constants
     const int rho = lane & 15, q = lane >> 4;
     int tokn[NT];
+    unsigned rowbit[NT];  // bit of the slot's row in the ownership masks, 0 for an unused slot
     int64_t orow[NT];  // (row * h + head) of the slot, -1 = unused slot
     unsigned nmask[NT];  // rows that have a slot in column tile n (wave uniform)
     x8 qf[NT][KS];
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
         const int slot = 16 * nn + rho, tok = slot / h, head = slot - tok * h;
         const bool used = tok < ntok;
         tokn[nn] = tok;
+        rowbit[nn] = used ? (1u << tok) : 0u;
         orow[nn] = used ? ((((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head) : -1;
         const int r_lo = (16 * nn) / h, r_hi = min((16 * nn + 15) / h, ntok - 1);
         nmask[nn] = r_lo <= r_hi ? bit_span(r_lo, r_hi) : 0u;
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
     };
     int cur = next_tile();
     if (cur >= 0) issue_dma(32 * cur);
+    int cw = -1;
+    unsigned fw = 0u, tw = 0u;
 
     while (cur >= 0) {
         const int nxt = next_tile();
@@ -264,10 +268,12 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
             }
         }
         // ownership of this tile: bit r of fullm / touchm = row r covers it completely / selected at least one of its keys
-        unsigned fw = 0u, tw = 0u;
-        if (lane < ntok) {
-            fw = fullw[lane * NW + (cur >> 5)];
-            tw = touchw[lane * NW + (cur >> 5)];
+        if ((cur >> 5) != cw) {  // lane r < ntok caches row r's bitmap words of the current 32-tile group (refreshed once per word)
+            cw = cur >> 5;
+            if (lane < ntok) {
+                fw = fullw[lane * NW + cw];
+                tw = touchw[lane * NW + cw];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffers may be refilled
         __builtin_amdgcn_sched_barrier(0);
@@ -353,12 +359,12 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) {
                 if (!(touchm & nmask[nn])) continue;
-                unsigned km = 0u;
-                if (orow[nn] >= 0) {
-                    if ((fullm >> tokn[nn]) & 1u) km = 0xffffffffu;
-                    else if ((partm >> tokn[nn]) & 1u) km = kmask[tokn[nn]];
+                const bool on = (fullm & rowbit[nn]) != 0u;
+                unsigned km = on ? 0xffffffffu : 0u;
+                if (partm) {
+                    if (partm & rowbit[nn]) km = kmask[tokn[nn]];
+                    km >>= 4 * q;  // bit 16u + j of km = key 16u + 4q + j of the tile
                 }
-                km >>= 4 * q;  // bit 16u + j of km = key 16u + 4q + j of the tile
                 f32x4 sacc[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -369,7 +375,6 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
                 float xs[8];
                 float tmax = -INFINITY;
                 if (partm == 0u) {  // every slot is all-on or all-off: one predicate per lane
-                    const bool on = km != 0u;
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
