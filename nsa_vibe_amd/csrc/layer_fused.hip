@@ -662,7 +662,7 @@ int launch_rmsnorm_rows(const void *x, const void *w, void *y, int M, int dim, f
 // A workgroup owns RMS_BWD_ROWS consecutive rows (one wave per row at a time); the per-column dw sums stay in registers across the
 // rows of a wave, are added over the 4 waves through LDS and leave as one fp32 partial row per workgroup; a second kernel adds the
 // partial rows in fixed order (no atomics: reproducible).  dim % 8 == 0, dim <= 4096.
-constexpr int RMS_BWD_ROWS = 32;
+constexpr int RMS_BWD_ROWS = 64;
 constexpr int RMS_BWD_CH = 8;  // 8-element chunks per lane: dim <= 512 * 8
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_rows_bwd_kernel(const T *__restrict__ x, const T *__restrict__ w, const T *__restrict__ dy,
@@ -726,13 +726,25 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_bwd_kernel(const T *__restri
     }
 }
 
+// dw[k] = sum over the workgroup partials, fixed order: a workgroup owns 64 columns, its 4 waves take every 4th partial row with 8
+// independent accumulators (the loads of 8 rows are in flight together; one dependent chain per column made this kernel 235 us)
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float *__restrict__ part, T *__restrict__ dw, int nparts, int dim) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= dim) return;
-    float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += part[(int64_t)p * dim + k];
-    dw[k] = Elt<T>::from_f(a);
+    __shared__ float red[4][64];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k < dim) {
+        int p = wave;
+        for (; p + 28 < nparts; p += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += part[(int64_t)(p + 4 * u) * dim + k];
+        }
+        for (; p < nparts; p += 4) acc[0] += part[(int64_t)p * dim + k];
+    }
+    red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (wave == 0 && k < dim) dw[k] = Elt<T>::from_f(((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]);
 }
 
 size_t rmsnorm_rows_bwd_workspace(int M, int dim) { return (size_t)((M + RMS_BWD_ROWS - 1) / RMS_BWD_ROWS) * dim * sizeof(float); }
@@ -744,7 +756,7 @@ static int launch_rmsnorm_bwd_t(const void *x, const void *w, const void *dy, vo
     hipLaunchKernelGGL(rmsnorm_rows_bwd_kernel<T>, dim3((unsigned)nparts), dim3(256), 0, st, (const T *)x, (const T *)w, (const T *)dy, (T *)dx,
                        part, M, dim, eps);
     NSA_LAUNCH_CHECK("rmsnorm_rows_bwd");
-    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<T>, dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, st, (const float *)part, (T *)dw, nparts,
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<T>, dim3((unsigned)((dim + 63) / 64)), dim3(256), 0, st, (const float *)part, (T *)dw, nparts,
                        dim);
     NSA_LAUNCH_CHECK("rmsnorm_dw_reduce");
     return NSA_OK;
