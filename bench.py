@@ -52,7 +52,7 @@ def make_inputs(nv, B, S, device, seed):
 
 def hot_path(nv, meta, Q, Kc, K, V, S):
     # causal_skip: scores of blocks that both selectors mask to -inf at row t are not computed
-    p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True)
+    p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
     # batched top-n (select_topn_ranges_batched semantics) + selection attention: one native call, the selector runs inside the
     # attention launch; the ranges are still materialised (they are an output of the path)
     return nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched")
@@ -75,9 +75,9 @@ def time_events(fn, iters, warm=2):
 def stage_times(nv, meta, Q, Kc, K, V, S, iters):
     """per-stage HIP-event times.  The step runs scores, then ONE launch that selects and attends (the selector runs inside the
     attention kernel): that launch is the dominant kernel of the roofline; the standalone select kernel is timed for reference."""
-    p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True)
+    p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
     ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
-    t_sc = time_events(lambda: nv.selection_scores(Q, Kc, meta, causal_skip=True), iters)
+    t_sc = time_events(lambda: nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True), iters)
     t_sel = time_events(lambda: nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S), iters)
     t_att = time_events(lambda: nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched"), iters)
     L = (ranges[..., 1] - ranges[..., 0]).clamp_min(0).sum(-1).double()

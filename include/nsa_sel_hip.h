@@ -271,7 +271,8 @@ NSA_API int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, 
  *   32/16/64) and bf16/f16 inputs with Dk in {64,128}, h <= 16, a single MFMA kernel evaluates Eq.9 in
  *   closed form; every other case runs the query-chunked generic path and needs the workspace.
  *   causal_skip != 0: entries p_grp[b,t,g,j] of blocks the selector can never pick at t
- *   ((j+1) l' > t+1, masked to -inf by both selectors) are returned as 0 instead of being computed.
+ *   ((j+1) l' > t+1, masked to -inf by both selectors) are returned as 0 instead of being computed; causal_skip == 2 leaves them
+ *   UNWRITTEN (saves the zero fill of p_grp -- 512 MiB at S = 64k; for callers that hand p_grp straight to the selectors).
  *   Few query rows (B*S*G <= 1024: decode) run a decode-shaped pair of kernels that spreads the K_cmp sweep of a
  *   row over many workgroups (any dtype / geometry); it needs B*S*G*h*S_cmp floats of workspace.
  *   variant: 0 auto, 1 generic, 2 MFMA (prefill), 3 decode-shaped.

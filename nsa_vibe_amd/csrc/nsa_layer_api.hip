@@ -204,7 +204,8 @@ int nsa_layer_prefill(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void
     // selected branch: scores (blocks no selector can read at row t are skipped) -> top-n + attention
     const bool aligned = ((uintptr_t)kv->K_cmp % 16 == 0) && kcb % 8 == 0 && kcg % 8 == 0 && Dk % 8 == 0;
     if (int rc = nsa_sel_scores(Q, kv->K_cmp, p_grp, B, S, G, h, Dk, n_cmp, kcb, kcg, Dk, csc_ptr, csc_rows, csc_vals, S_sel, L->l, L->d,
-                                L->l_sel, 1, aligned ? 0 : 1, dt, scale, ws + W.sc, W.sc_bytes, stream))
+                                L->l_sel, 2 /* skipped blocks stay unwritten: only the selector below reads p_grp */, aligned ? 0 : 1, dt, scale, ws + W.sc,
+                                W.sc_bytes, stream))
         return rc;
     if (int rc = nsa_sel_select_attn_fwd(p_grp, 0, nullptr, S_sel, L->l_sel, L->n_sel, 1, 2, selector, S, ranges_out, out_width, Q, kv->K_sel,
                                          kv->V_sel, Osel, nullptr, B, S, G, h, Dk, Dv, S, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale, ws + W.att,

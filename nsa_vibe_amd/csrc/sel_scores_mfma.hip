@@ -280,8 +280,9 @@ int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, i
                   "scores_mfma: Q/K_cmp must be 16-byte aligned with strides that are multiples of 8 elements");
     NSA_CHECK_ARG((int64_t)B * G <= 65535, "scores_mfma: B*G too large for one launch");
     NSA_CHECK_ARG(S_cmp >= 1, "scores_mfma: S_cmp must be >= 1");
-    // blocks the second sweep does not visit (causal skip, or selection blocks without any compressed row) are zero
-    NSA_HIP_TRY(hipMemsetAsync(p_grp, 0, sizeof(float) * (size_t)B * S * G * S_sel, st));
+    // blocks the second sweep does not visit (causal skip, or selection blocks without any compressed row) are zero -- unless the caller
+    // asked for causal_skip == 2: it then reads only entries with (j+1) l' <= t+1 (what both selectors do), all of which are written
+    if (causal_skip != 2) NSA_HIP_TRY(hipMemsetAsync(p_grp, 0, sizeof(float) * (size_t)B * S * G * S_sel, st));
     ScoresMfmaParams P{Q, Kc, p_grp, B, S, G, h, S_cmp, S_sel, csb, csg, css, scale, causal_skip, d_stride};
     if (dtype == NSA_DT_BF16) return Dk == 64 ? launch_scores_t<__bf16, 64>(P, st) : launch_scores_t<__bf16, 128>(P, st);
     return Dk == 64 ? launch_scores_t<_Float16, 64>(P, st) : launch_scores_t<_Float16, 128>(P, st);

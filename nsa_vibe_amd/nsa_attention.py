@@ -348,7 +348,7 @@ class NSAAttention(nn.Module):
         scale = 1.0 / math.sqrt(self.d_k)
         Qc = Q.contiguous()
         # ---- selected branch (HIP): scores -> ranges -> attention
-        p_grp = selection_scores(Qc, kv.K_cmp, meta, scale, causal_skip=True)
+        p_grp = selection_scores(Qc, kv.K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
         if self.selector == "batched":
             ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
         else:
@@ -406,7 +406,7 @@ class NSAAttention(nn.Module):
         meta = kv.ensure_meta(S)
         scale = 1.0 / math.sqrt(self.d_k)
         with torch.no_grad():  # the selection itself is not differentiable (top-n indices)
-            p_grp = selection_scores(Q.detach(), kv.K_cmp, meta, scale, causal_skip=True)
+            p_grp = selection_scores(Q.detach(), kv.K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
             if self.selector == "batched":
                 ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
             else:

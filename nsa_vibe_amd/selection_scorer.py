@@ -113,12 +113,13 @@ def group_reduce_pslc(p_slc: torch.Tensor) -> torch.Tensor:
 
 
 def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, scale: Optional[float] = None,
-                     causal_skip: bool = False, variant: int = 0) -> torch.Tensor:
+                     causal_skip: bool = False, variant: int = 0, leave_skipped: bool = False) -> torch.Tensor:
     """Fused A2+A3+A4: Q [B,S,G,h,Dk], K_cmp [B,G,S_cmp,Dk] -> p_grp [B,S,G,S_sel] fp32 without
     materialising p_cmp (nsa_attention.py:1073-1091 in one call).
 
     causal_skip=True returns 0 for the blocks neither selector can pick at row t ((j+1) l' > t+1; both mask
-    them to -inf, selection_scorer.py:156,276-280) instead of computing them.  variant: 0 auto, 1 generic
+    them to -inf, selection_scorer.py:156,276-280) instead of computing them; with leave_skipped=True those entries are left
+    uninitialised (no zero fill of the tensor) -- for results that go straight to the selectors.  variant: 0 auto, 1 generic
     (any dtype/geometry, query-chunked), 2 the MFMA kernel (bf16/f16, default block geometry)."""
     dev = _need_gpu(Q_all, K_cmp)
     B, S, G, h, Dk = Q_all.shape
@@ -137,7 +138,7 @@ def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, 
     cptr, crows, cvals = meta.device_csc(dev)
     rc = L.nsa_sel_scores(Q_all.data_ptr(), K_cmp.data_ptr(), p_grp.data_ptr(), B, S, G, h, Dk, S_cmp, sb, sg, ss,
                           cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(), S_sel, int(meta.l), int(meta.d), int(meta.l_sel),
-                          int(bool(causal_skip)), int(variant), _DT[Q_all.dtype], float(scale) if scale else 0.0,
+                          (2 if leave_skipped else 1) if causal_skip else 0, int(variant), _DT[Q_all.dtype], float(scale) if scale else 0.0,
                           ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(dev))
     _lib.check(rc, "nsa_sel_scores")
     return p_grp

@@ -361,3 +361,29 @@ def test_262144_tokens_selector(nv, orc):
         r = nv.select_topn_ranges(p, m, n, t).cpu().numpy()
         ref = orc.select_topn_ranges(p.cpu().numpy(), om, n, t)
         assert orc.normalise_ranges(r) == orc.normalise_ranges(ref), t
+
+
+def test_scores_leave_skipped_entries_unwritten_same_selection(nv):
+    """causal_skip with leave_skipped=True (no zero fill of p_grp): every entry a selector may read equals the zero-filled result, so
+    ranges and attention are identical; the tensor is pre-poisoned with NaN to prove nothing unwritten is read"""
+    torch.manual_seed(4)
+    B, S, G, h, D = 2, 1100, 2, 6, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    Kc = torch.randn(B, G, meta.S_cmp, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    ref = nv.selection_scores(Q, Kc, meta, causal_skip=True)
+    # poison the allocator's next block of this size, then ask for the unwritten form
+    poison = torch.full_like(ref, float("nan"))
+    del poison
+    got = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
+    t = torch.arange(S, device="cuda")
+    valid = (torch.arange(meta.S_sel, device="cuda")[None, :] + 1) * 64 <= (t[:, None] + 1)  # [S,S_sel]
+    m = valid[None, :, None, :].expand_as(ref)
+    assert torch.equal(got[m], ref[m])
+    for mode in ("batched", "sequential"):
+        r0, o0 = nv.select_and_attend(ref, Q, K, V, meta, 16, mode=mode, scale=0.125)
+        r1, o1 = nv.select_and_attend(got, Q, K, V, meta, 16, mode=mode, scale=0.125)
+        assert torch.equal(r0, r1) and torch.equal(o0, o1)
+    assert torch.equal(nv.select_topn_ranges_batched(got, meta, 16, S), nv.select_topn_ranges_batched(ref, meta, 16, S))
