@@ -68,6 +68,31 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
     unsigned *touchw = fullw + tpw * NW;                      // [tpw][NW]
     unsigned *kmask = touchw + tpw * NW;                      // [16]
 
+    // ---- per-slot constants; the Q loads are issued first so that their latency runs under the range / bitmap work below
+    const int rho = lane & 15, q = lane >> 4;
+    int tokn[NT];
+    unsigned rowbit[NT];  // bit of the slot's row in the ownership masks, 0 for an unused slot
+    int64_t orow[NT];  // (row * h + head) of the slot, -1 = unused slot
+    unsigned nmask[NT];  // rows that have a slot in column tile n (wave uniform)
+    x8 qf[NT][KS];
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+        const int slot = 16 * nn + rho, tok = slot / h, head = slot - tok * h;
+        const bool used = tok < ntok;
+        tokn[nn] = tok;
+        rowbit[nn] = used ? (1u << tok) : 0u;
+        orow[nn] = used ? ((((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head) : -1;
+        const int r_lo = (16 * nn) / h, r_hi = min((16 * nn + 15) / h, ntok - 1);
+        nmask[nn] = r_lo <= r_hi ? bit_span(r_lo, r_hi) : 0u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (used) raw = *(const u32x4 *)((const T *)P.Q + orow[nn] * D + 32 * s + 8 * q);
+            qf[nn][s] = __builtin_bit_cast(x8, raw);
+        }
+    }
+    const unsigned usedmask = bit_span(0, ntok - 1);
+
     // ---- (1) bitmaps cleared, ranges of the rows -> LDS
     for (int i = lane; i < 2 * tpw * NW + 16; i += 64) fullw[i] = 0u;
     for (int r = 0; r < ntok; ++r) {
@@ -125,31 +150,6 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
         if (lane + 64 < NW) u1 |= touchw[r * NW + 64 + lane];
     }
     unsigned long long nz0 = __ballot(u0 != 0u), nz1 = __ballot(u1 != 0u);
-
-    // ---- per-slot constants
-    const int rho = lane & 15, q = lane >> 4;
-    int tokn[NT];
-    unsigned rowbit[NT];  // bit of the slot's row in the ownership masks, 0 for an unused slot
-    int64_t orow[NT];  // (row * h + head) of the slot, -1 = unused slot
-    unsigned nmask[NT];  // rows that have a slot in column tile n (wave uniform)
-    x8 qf[NT][KS];
-#pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
-        const int slot = 16 * nn + rho, tok = slot / h, head = slot - tok * h;
-        const bool used = tok < ntok;
-        tokn[nn] = tok;
-        rowbit[nn] = used ? (1u << tok) : 0u;
-        orow[nn] = used ? ((((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head) : -1;
-        const int r_lo = (16 * nn) / h, r_hi = min((16 * nn + 15) / h, ntok - 1);
-        nmask[nn] = r_lo <= r_hi ? bit_span(r_lo, r_hi) : 0u;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            u32x4 raw = {0u, 0u, 0u, 0u};
-            if (used) raw = *(const u32x4 *)((const T *)P.Q + orow[nn] * D + 32 * s + 8 * q);
-            qf[nn][s] = __builtin_bit_cast(x8, raw);
-        }
-    }
-    const unsigned usedmask = bit_span(0, ntok - 1);
 
     const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
     const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
