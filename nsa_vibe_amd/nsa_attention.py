@@ -73,8 +73,38 @@ class GateMLP(nn.Module):
         self.fc2 = nn.Linear(hidden, 3)
         nn.init.xavier_uniform_(self.fc2.weight, gain=0.1)
         nn.init.zeros_(self.fc2.bias)
+        # debugging overrides of the reference, read once at construction like there (nsa_attention.py:42-48)
+        self._force_uniform_gate = os.getenv("NSA_FORCE_UNIFORM_GATE", "0").lower() in ("1", "true", "yes")
+        fb = (os.getenv("NSA_FORCE_BRANCH") or "").strip().lower()
+        self._force_branch = fb if fb in ("cmp", "sel", "win") else None
+        self._forced_fc2 = None
+
+    def forced(self) -> bool:
+        return self._force_uniform_gate or self._force_branch is not None
+
+    def fc2_params(self):
+        """(weight, bias) of fc2 as the kernels should see them: the real parameters, or -- under NSA_FORCE_UNIFORM_GATE / NSA_FORCE_BRANCH --
+        constants that make the same kernels emit exactly 1/3,1/3,1/3 resp. the one-hot of the forced branch (zero weight; bias 0 resp.
+        +-1000, which is beyond the one-hot threshold of 50)"""
+        if not self.forced():
+            return self.fc2.weight, self.fc2.bias
+        w = self.fc2.weight
+        key = (w.device, w.dtype)
+        if self._forced_fc2 is None or self._forced_fc2[0] != key:
+            b = torch.zeros(3, device=w.device, dtype=w.dtype)
+            if not self._force_uniform_gate:
+                b.fill_(-1000.0)
+                b[("cmp", "sel", "win").index(self._force_branch)] = 1000.0
+            self._forced_fc2 = (key, torch.zeros_like(w).detach(), b)
+        return self._forced_fc2[1], self._forced_fc2[2]
 
     def forward(self, q_pooled: torch.Tensor, tau: float = 1.0) -> torch.Tensor:
+        if self._force_uniform_gate:  # reference :51-57
+            return torch.full((*q_pooled.shape[:-1], 3), 1.0 / 3.0, device=q_pooled.device, dtype=q_pooled.dtype)
+        if self._force_branch is not None:  # reference :58-70
+            one = torch.zeros((*q_pooled.shape[:-1], 3), device=q_pooled.device, dtype=q_pooled.dtype)
+            one[..., ("cmp", "sel", "win").index(self._force_branch)] = 1.0
+            return one
         g = self.fc2(F.silu(self.fc1(q_pooled))) / max(tau, 1e-6)
         p = F.softmax(g, dim=-1)
         peaked = _top2_gap(g.detach()) > 50.0  # hard one-hot when extremely peaked (reference :70-81), sync free
@@ -277,7 +307,7 @@ class NSAAttention(nn.Module):
     def _layer_desc(self):
         """(nsa_layer_desc, fused W_qkv) -- rebuilt when a parameter was modified or moved (tensor version counters)"""
         ps = [getattr(self, n).weight for n in self._QKV] + [self.out.weight, self.gate.fc1.weight, self.gate.fc1.bias,
-                                                               self.gate.fc2.weight, self.gate.fc2.bias]
+                                                               *self.gate.fc2_params()]
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_desc_key", None) != key or self._desc_keep[0].dtype != ps[0].dtype:
             W_qkv = torch.cat([p.detach() for p in ps[:7]], dim=0).contiguous()
@@ -415,7 +445,7 @@ class NSAAttention(nn.Module):
         O_sel = selection_attention_hip(Q, K_sel, V_sel, ranges, scale=scale)
         O_cmp = batched_causal_attention_compressed(Q, K_cmp, V_cmp, self.l, self.d, scale=scale)
         O_win = sliding_window_attention(Q, K_win, V_win, self.w, scale=scale)
-        O = _GateCombineFn.apply(Q, O_cmp, O_sel, O_win, self.gate.fc1.weight, self.gate.fc1.bias, self.gate.fc2.weight, self.gate.fc2.bias,
+        O = _GateCombineFn.apply(Q, O_cmp, O_sel, O_win, self.gate.fc1.weight, self.gate.fc1.bias, *self.gate.fc2_params(),
                                  self)
         return self.out(O.reshape(B, S, self.n_heads * self.d_v)), kv
 

@@ -28,6 +28,17 @@ def _prep_kv(X: torch.Tensor) -> torch.Tensor:
 
 
 def _prep_ranges(ranges: torch.Tensor) -> torch.Tensor:
+    """[B,S,G,n,2] int32 contiguous.  Like the reference's range normaliser (kernels/triton_sel_kernel/__init__.py:17-39) extra singleton
+    dimensions are squeezed away and a 4-D tensor is taken as batch-less; the clamp to [0,S_kv] happens in the kernels."""
+    while ranges.dim() > 5:
+        d = next((i for i in range(ranges.dim()) if ranges.size(i) == 1), None)
+        if d is None:
+            break
+        ranges = ranges.squeeze(d)
+    if ranges.dim() == 4:
+        ranges = ranges.unsqueeze(0)
+    if ranges.dim() != 5 or ranges.shape[-1] != 2:
+        raise ValueError(f"ranges must be [B,S,G,n,2] (start,end), got {tuple(ranges.shape)}")
     if ranges.dtype != torch.int32:
         ranges = ranges.to(torch.int32)  # a copy: the caller's tensor stays untouched
     return ranges.contiguous()

@@ -222,3 +222,43 @@ def test_kv_cache_grows_in_place_of_the_reference_cat(nv):
     fixed = NSA_KV(1, 1, 8, 8, 4, 4, 2, 8, 2, 16, "cpu", torch.float32, auto_grow=False)
     with pytest.raises(RuntimeError, match="capacity exceeded"):
         fixed.write_tokens(*[torch.zeros(1, 1, 5, 8) for _ in range(6)])
+
+
+def test_ranges_shape_normalisation_like_the_reference_wrapper():
+    """over-nested (extra singleton dims) and batch-less ranges are accepted as the reference's wrapper accepts them
+    (test_ranges_normalization.py:6-24); anything else is a ValueError; the caller's int64 tensor is never modified"""
+    from nsa_vibe_amd.selection_attention import _prep_ranges
+
+    t6 = torch.zeros((1, 1, 2, 1, 1, 2), dtype=torch.int32)
+    assert _prep_ranges(t6).shape == (1, 2, 1, 1, 2) or _prep_ranges(t6).dim() == 5
+    t4 = torch.tensor([[[[0, 10], [40, 60]]]], dtype=torch.int64)
+    keep = t4.clone()
+    out = _prep_ranges(t4)
+    assert out.shape == (1, 1, 1, 2, 2) and out.dtype == torch.int32 and out.is_contiguous() and torch.equal(t4, keep)
+    with pytest.raises(ValueError):
+        _prep_ranges(torch.zeros((2, 3, 4), dtype=torch.int32))
+    with pytest.raises(ValueError):
+        _prep_ranges(torch.zeros((1, 1, 1, 2, 3), dtype=torch.int32))
+
+
+@pytest.mark.parametrize("flag,idx", [("cmp", 0), ("sel", 1), ("win", 2)])
+def test_gate_force_branch_env_like_the_reference(flag, idx, monkeypatch):
+    """NSA_FORCE_BRANCH / NSA_FORCE_UNIFORM_GATE are read at construction and override the gate (reference test_force_branch_gates.py,
+    nsa_attention.py:42-70); the kernel-side parameters (fc2_params) encode the same override"""
+    from nsa_vibe_amd.nsa_attention import GateMLP
+
+    monkeypatch.setenv("NSA_FORCE_BRANCH", flag)
+    g = GateMLP(d_k=8)
+    p = g(torch.randn(2, 3, 8))
+    assert p.shape == (2, 3, 3) and torch.all(torch.argmax(p, dim=-1) == idx) and torch.allclose(p.sum(-1), torch.ones(2, 3))
+    w2, b2 = g.fc2_params()
+    assert not w2.any() and int(torch.argmax(b2)) == idx and float(b2.max() - b2.min()) > 50.0
+    monkeypatch.delenv("NSA_FORCE_BRANCH")
+    monkeypatch.setenv("NSA_FORCE_UNIFORM_GATE", "1")
+    u = GateMLP(d_k=8)
+    assert torch.allclose(u(torch.randn(4, 8)), torch.full((4, 3), 1.0 / 3.0))
+    w2, b2 = u.fc2_params()
+    assert not w2.any() and not b2.any()
+    monkeypatch.delenv("NSA_FORCE_UNIFORM_GATE")
+    plain = GateMLP(d_k=8)
+    assert plain.fc2_params()[0] is plain.fc2.weight and not plain.forced()

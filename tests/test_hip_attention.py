@@ -444,3 +444,19 @@ def test_backward_query_tile_dq_long_context_and_kernel_switch(nv, monkeypatch):
     for a, b_ in zip(res["0"], res["1"]):
         assert torch.isfinite(a).all() and (a.float() - b_.float()).abs().max().item() <= 2e-2 * max(1.0, a.float().abs().max().item())
     assert not res["1"][0][0, 2, 0].any()  # empty row: zero gradient
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_backward_all_ranges_empty_gives_zero_gradients(nv, variant):
+    """the reference's edge case (test_selection_backward_edges.py:28-47): forward is zero, every gradient is zero -- and finite"""
+    torch.manual_seed(0)
+    B, S, G, h, D, S_kv = 2, 9, 2, 6, 64, 130
+    q = torch.randn(B, S, G, h, D, device="cuda").bfloat16().requires_grad_(True)
+    k = torch.randn(B, G, S_kv, D, device="cuda").bfloat16().requires_grad_(True)
+    v = torch.randn(B, G, S_kv, D, device="cuda").bfloat16().requires_grad_(True)
+    rg = torch.tensor([[0, 0], [4, 4], [9, 3]], dtype=torch.int64, device="cuda").expand(B, S, G, 3, 2).contiguous()
+    o = nv.selection_attention_hip(q, k, v, rg, variant=variant)
+    assert not o.any()
+    o.backward(torch.randn_like(o))
+    for t in (q, k, v):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and not t.grad.any()

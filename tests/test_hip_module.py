@@ -572,3 +572,36 @@ def test_rmsnorm_native_forward_backward_match_the_eager_chain(dtype, shape, mon
         assert (a - e).abs().max().item() <= bound, (name, (a - e).abs().max().item(), scale)
     if dtype == torch.bfloat16:
         assert torch.equal(res["native"][0], res["eager"][0])
+
+
+@pytest.mark.parametrize("flag", ["cmp", "sel", "win", "uniform"])
+def test_force_branch_and_uniform_gate_flags_reach_the_native_paths(flag, monkeypatch):
+    """the reference's gate overrides (NSA_FORCE_BRANCH, NSA_FORCE_UNIFORM_GATE; bench_decode --branch_force_mode env uses them) act on
+    the fused prefill / decode kernels exactly as on the eager gate: native == eager composition, gates are one-hot resp. 1/3"""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    if flag == "uniform":
+        monkeypatch.setenv("NSA_FORCE_UNIFORM_GATE", "1")
+    else:
+        monkeypatch.setenv("NSA_FORCE_BRANCH", flag)
+    torch.manual_seed(17)
+    m = NSAAttention(256, 8, 2, 64, 64, l=32, d=16, l_sel=64, n_sel=4, w=96).cuda().float().eval()
+    B, S, n_dec = 2, 150, 6
+    x = torch.randn(B, S + n_dec, 256, device="cuda")
+    outs = {}
+    for mode in ("native", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        else:
+            monkeypatch.delenv("NSA_HIP_EAGER_TRAIN", raising=False)
+        kv = m.new_kv(B, S + n_dec, "cuda", torch.float32)
+        with torch.set_grad_enabled(mode == "eager"):
+            o, kv = m(x[:, :S], kv, prefill=True)
+            g_pre = m._last_gates.detach().float().reshape(-1, 3).clone()
+            dec = [m(x[:, t: t + 1], kv, prefill=False)[0].detach() for t in range(S, S + n_dec)]
+        outs[mode] = (o.detach(), torch.cat(dec, dim=1), g_pre)
+    want = torch.full((3,), 1.0 / 3.0) if flag == "uniform" else torch.eye(3)[("cmp", "sel", "win").index(flag)]
+    for mode in outs:
+        assert torch.allclose(outs[mode][2].cpu(), want.expand_as(outs[mode][2].cpu()), atol=1e-6)
+    for a, e in zip(outs["native"][:2], outs["eager"][:2]):
+        assert (a - e).abs().max().item() <= 5e-4
