@@ -22,16 +22,22 @@ from .selection_attention import (  # noqa: F401
 )
 from .selection_scorer import (  # noqa: F401
     batched_ranges_width,
+    compute_pcmp,
     compute_pcmp_all,
+    convert_indices_to_ranges_batched,
+    convert_indices_to_ranges_batched_dispatch,
     convert_indices_to_ranges_batched_v2,
     group_reduce_pslc,
     map_pcmp_to_pgrp,
     map_pcmp_to_pslc,
     map_pcmp_to_pslc_batched,
+    map_pcmp_to_pslc_slow_path,
     select_topn_ranges,
     select_topn_ranges_batched,
     select_topn_ranges_rows,
     selection_scores,
+    validate_selection_determinism,
+    verify_mapping_equivalence,
 )
 
 __version__ = "0.1.0"

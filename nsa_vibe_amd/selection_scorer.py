@@ -213,3 +213,62 @@ def convert_indices_to_ranges_batched_v2(indices: torch.Tensor, meta: BlockMeta,
 
 
 convert_indices_to_ranges_batched_dispatch = convert_indices_to_ranges_batched_v2
+
+
+# ---- the rest of the reference's scorer surface: per-step form, converter names, verifiers --------------------------------------
+def compute_pcmp(Q: torch.Tensor, K_cmp: torch.Tensor, scale: float) -> torch.Tensor:
+    """Single-step form (selection_scorer.py:10-39): Q [B,G,h,Dk] (or [G,h,Dk] with an implicit batch of one), K_cmp [B,G,S_cmp,Dk]
+    -> p_cmp [B,G,h,S_cmp], the softmax over all S_cmp columns."""
+    if Q.dim() == 3:
+        Q = Q.unsqueeze(0)
+    return compute_pcmp_all(Q.unsqueeze(1), K_cmp, scale)[:, 0]
+
+
+def convert_indices_to_ranges_batched(indices: torch.Tensor, meta: BlockMeta, S: int) -> torch.Tensor:
+    """The reference's loop converter (selection_scorer.py:380-431) and its vectorised v2 (:434-605) define the same function (pinned
+    by the g3 goldens); both names run the one HIP converter."""
+    return convert_indices_to_ranges_batched_v2(indices, meta, S)
+
+
+convert_indices_to_ranges_batched_dispatch = convert_indices_to_ranges_batched  # selection_scorer.py:365-377 (NSA_SEL_RANGES_V2 switch)
+
+
+def map_pcmp_to_pslc_slow_path(p_cmp_all: torch.Tensor, meta: BlockMeta) -> torch.Tensor:
+    """Eq.9 as a plain dense product p_cmp . M (M [S_cmp,S_sel] from the CSR arrays): the reference's "slow mathematical path"
+    (selection_scorer.py:608-655) used to verify the fast mapping.  A checker, not a product path."""
+    S_cmp = p_cmp_all.shape[-1]
+    rows = meta.M_csl_coo_indices[0].long()
+    keep = rows < S_cmp
+    M = torch.zeros((S_cmp, meta.S_sel), dtype=torch.float32)
+    M.index_put_((rows[keep], meta.M_csl_coo_indices[1].long()[keep]), meta.M_csl_coo_values.float()[keep], accumulate=True)
+    return (p_cmp_all.to(torch.float32) @ M.to(p_cmp_all.device)).to(p_cmp_all.dtype)
+
+
+def verify_mapping_equivalence(p_cmp_all: torch.Tensor, meta: BlockMeta, rtol: float = 1e-5, atol: float = 1e-8):
+    """(ok, details) like the reference's verifier (selection_scorer.py:658-711): the HIP mapping against the dense product; runs only
+    when NSA_VERIFY_EQ9_MAPPING is set, otherwise reports "skipped"."""
+    import os
+
+    if os.getenv("NSA_VERIFY_EQ9_MAPPING", "0").lower() not in ("1", "true", "yes"):
+        return True, {"status": "skipped", "reason": "NSA_VERIFY_EQ9_MAPPING not set"}
+    with torch.no_grad():
+        fast = map_pcmp_to_pslc_batched(p_cmp_all, meta).float()
+        slow = map_pcmp_to_pslc_slow_path(p_cmp_all, meta).float()
+        diff = (fast - slow).abs()
+        ok = bool(torch.allclose(fast, slow, rtol=rtol, atol=atol))
+        return ok, {"status": "verified" if ok else "mismatch", "max_abs_diff": float(diff.max()) if diff.numel() else 0.0,
+                    "mean_abs_diff": float(diff.mean()) if diff.numel() else 0.0,
+                    "max_rel_diff": float((diff / (slow.abs() + atol)).max()) if diff.numel() else 0.0,
+                    "shape": list(p_cmp_all.shape), "rtol": rtol, "atol": atol}
+
+
+def validate_selection_determinism(p_grp: torch.Tensor, meta: BlockMeta, n_top: int, t_token: int, num_trials: int = 5) -> bool:
+    """Repeat the sequential selector and compare (selection_scorer.py:714-760); runs only when NSA_VALIDATE_SELECTION_DETERMINISM is
+    set.  The HIP selector has no atomics and a fixed tie rule, so this is a regression guard rather than a live risk."""
+    import os
+
+    if os.getenv("NSA_VALIDATE_SELECTION_DETERMINISM", "0").lower() not in ("1", "true", "yes") or p_grp.requires_grad:
+        return True
+    with torch.no_grad():
+        first = select_topn_ranges(p_grp.clone(), meta, n_top, t_token, True, 2)
+        return all(torch.equal(first, select_topn_ranges(p_grp.clone(), meta, n_top, t_token, True, 2)) for _ in range(num_trials - 1))

@@ -262,3 +262,19 @@ def test_gate_force_branch_env_like_the_reference(flag, idx, monkeypatch):
     monkeypatch.delenv("NSA_FORCE_UNIFORM_GATE")
     plain = GateMLP(d_k=8)
     assert plain.fc2_params()[0] is plain.fc2.weight and not plain.forced()
+
+
+def test_eq9_slow_path_matches_the_oracle_mapping(nv, orc):
+    """map_pcmp_to_pslc_slow_path (dense p . M, the reference's verifier path selection_scorer.py:608-655) == the oracle's Eq.9 stencil"""
+    rng = np.random.default_rng(5)
+    S = 1000
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    om = orc.build_block_meta(S, 32, 16, 64, 16, 512)
+    p = rng.random((1, 3, 2, 4, meta.S_cmp), dtype=np.float32)
+    p_slc, _ = orc.map_pcmp_to_pslc_and_pgrp(p, om)
+    got = nv.map_pcmp_to_pslc_slow_path(torch.from_numpy(p), meta).numpy()
+    assert np.abs(got - p_slc).max() <= 1e-6
+    short = nv.map_pcmp_to_pslc_slow_path(torch.from_numpy(p[..., :10]), meta)  # fewer compressed rows than the meta covers
+    assert short.shape[-1] == meta.S_sel and not short[..., 4:].any()
+    ok, info = nv.verify_mapping_equivalence(torch.from_numpy(p), meta)
+    assert ok and info["status"] == "skipped"

@@ -387,3 +387,28 @@ def test_scores_leave_skipped_entries_unwritten_same_selection(nv):
         r1, o1 = nv.select_and_attend(got, Q, K, V, meta, 16, mode=mode, scale=0.125)
         assert torch.equal(r0, r1) and torch.equal(o0, o1)
     assert torch.equal(nv.select_topn_ranges_batched(got, meta, 16, S), nv.select_topn_ranges_batched(ref, meta, 16, S))
+
+
+def test_per_step_scorer_names_and_verifiers(nv, orc, monkeypatch):
+    """compute_pcmp (per-step form, with and without the batch axis), the converter's three names, and the two opt-in verifiers of the
+    reference's scorer module (selection_scorer.py:10-39, 365-431, 658-760) on the HIP kernels"""
+    torch.manual_seed(2)
+    B, G, h, D, S = 2, 2, 4, 64, 700
+    meta = nv.build_block_meta(S, 32, 16, 64, 8, 128)
+    Q = torch.randn(B, G, h, D, device="cuda")
+    Kc = torch.randn(B, G, meta.S_cmp, D, device="cuda")
+    p = nv.compute_pcmp(Q, Kc, 0.125)
+    ref = torch.softmax(torch.einsum("bghd,bgcd->bghc", Q, Kc) * 0.125, dim=-1)
+    assert p.shape == (B, G, h, meta.S_cmp) and (p - ref).abs().max().item() <= 1e-6
+    p1 = nv.compute_pcmp(Q[0], Kc[:1], 0.125)
+    assert p1.shape == (1, G, h, meta.S_cmp) and torch.equal(p1[0], p[0])
+    idx = torch.tensor([[[[0, 1, 2, 5, 6, -1]]]], dtype=torch.int32, device="cuda").expand(1, 3, 2, 6).contiguous()
+    a, b_, c = (f(idx, meta, 3) for f in (nv.convert_indices_to_ranges_batched, nv.convert_indices_to_ranges_batched_dispatch,
+                                          nv.convert_indices_to_ranges_batched_v2))
+    assert torch.equal(a, b_) and torch.equal(a, c)
+    monkeypatch.setenv("NSA_VERIFY_EQ9_MAPPING", "1")
+    ok, info = nv.verify_mapping_equivalence(p.unsqueeze(1), meta)
+    assert ok and info["status"] == "verified" and info["max_abs_diff"] <= 1e-6
+    monkeypatch.setenv("NSA_VALIDATE_SELECTION_DETERMINISM", "1")
+    p_grp = nv.map_pcmp_to_pgrp(p, meta)
+    assert nv.validate_selection_determinism(p_grp, meta, 8, S - 1)
