@@ -13,7 +13,12 @@ from .band_attention import (  # noqa: F401
 )
 from .block_index import BlockMeta, build_block_meta, build_block_starts, build_M_csl_csr  # noqa: F401
 from .selection_attention import (  # noqa: F401
+    grouped_selection_attention,
     grouped_selection_attention_masked,
+    grouped_selection_attention_packed,
+    selection_attention_cuda,
+    selection_attention_varlen_all,
+    selection_attention_varlen_all_v2,
     hip_sel_available,
     select_and_attend,
     selection_attention_first_key_parity,

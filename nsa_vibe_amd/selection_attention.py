@@ -216,6 +216,14 @@ def select_and_attend(p_grp: torch.Tensor, Q: torch.Tensor, K: torch.Tensor, V: 
 # the reference's executor names, bound to the HIP implementation
 grouped_selection_attention_masked = selection_attention_hip
 selection_attention_cuda = selection_attention_hip
+# the "merged-range varlen gather" executors (attention_kernels.py:391-542, 545-702) compute the same masked softmax through an FA-2
+# varlen pack; here the gather is what the kernels do anyway
+selection_attention_varlen_all = selection_attention_hip
+selection_attention_varlen_all_v2 = selection_attention_hip
+# the default packed / gather executors are first-gathered-key functions (see selection_attention_first_key_parity): their names are
+# bound to that parity mode, NOT to the semantic executor, so that code calling them by name keeps the reference's numbers
+grouped_selection_attention_packed = selection_attention_first_key_parity
+grouped_selection_attention = selection_attention_first_key_parity
 
 
 def hip_sel_available() -> bool:
