@@ -242,7 +242,7 @@ class NSAAttention(nn.Module):
             selector = "batched" if os.getenv("NSA_PREFILL_BATCHED", "0").lower() in ("1", "true", "yes") else "sequential"
         assert selector in ("sequential", "batched")
         self.selector = selector
-        self.query_chunk = query_chunk
+        self.query_chunk = query_chunk  # reserved: the fused scorer never materialises p_cmp, so prefill is not query-chunked (p_grp is 512 MiB at 64k)
         self.W_Q = nn.Linear(dim, n_heads * d_k, bias=False)
         self.W_K_sel = nn.Linear(dim, n_kv_groups * d_k, bias=False)
         self.W_V_sel = nn.Linear(dim, n_kv_groups * d_v, bias=False)
