@@ -457,6 +457,9 @@ __global__ __launch_bounds__(256) void bwd_dq_rows_kernel(SelAttnBwdParams P, co
     for (int m = 0; m < 4; ++m) dq[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int cur = next_tile();
     if (cur >= 0) issue_dma(32 * cur);
+    int cw = -1;
+    unsigned fw = 0u, tw = 0u;
+    const unsigned rowbit = live ? (1u << tok) : 0u;
     while (cur >= 0) {
         const int nxt = next_tile();
         const int tok0 = 32 * cur;
@@ -474,10 +477,12 @@ __global__ __launch_bounds__(256) void bwd_dq_rows_kernel(SelAttnBwdParams P, co
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int m = 0; m < 4; ++m) ktr[u][m] = tr_read<x4>(k_tr + rd_tr[m] + u * 16 * BROWB);
-        unsigned fw = 0u, tw = 0u;
-        if (lane < ntok) {
-            fw = fullw[lane * NW + (cur >> 5)];
-            tw = touchw[lane * NW + (cur >> 5)];
+        if ((cur >> 5) != cw) {  // lane r < ntok caches row r's bitmap words of the current 32-tile group
+            cw = cur >> 5;
+            if (lane < ntok) {
+                fw = fullw[lane * NW + cw];
+                tw = touchw[lane * NW + cw];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -495,12 +500,12 @@ __global__ __launch_bounds__(256) void bwd_dq_rows_kernel(SelAttnBwdParams P, co
             }
             wave_lds_fence();
         }
-        unsigned km = 0u;
-        if (live) {
-            if ((fullm >> tok) & 1u) km = 0xffffffffu;
-            else if ((partm >> tok) & 1u) km = kmask[tok];
+        const bool on = (fullm & rowbit) != 0u;
+        unsigned km = on ? 0xffffffffu : 0u;
+        if (partm) {
+            if (partm & rowbit) km = kmask[tok];
+            km >>= 4 * q;  // bit 16u + j = key 16u + 4q + j of the tile
         }
-        km >>= 4 * q;  // bit 16u + j = key 16u + 4q + j of the tile
 
         f32x4 sacc[2], pacc[2];
 #pragma unroll
@@ -519,7 +524,8 @@ __global__ __launch_bounds__(256) void bwd_dq_rows_kernel(SelAttnBwdParams P, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][j], c2, -lse2));
-                if (!((km >> (16 * u + j)) & 1u)) p = 0.f;
+                if (partm == 0u) p = on ? p : 0.f;  // every slot all-on or all-off: one predicate per lane (wave-uniform branch)
+                else if (!((km >> (16 * u + j)) & 1u)) p = 0.f;
                 dsf[4 * u + j] = Elt<T>::from_f(p * (pacc[u][j] - dlt) * P.scale);
             }
 #pragma unroll
