@@ -19,6 +19,7 @@
  *                              grouped_selection_attention_masked   nsa/core/attention_kernels.py:705-772 (semantics)
  *   nsa_sel_attn_first_key_parity  grouped_selection_attention_packed / grouped_selection_attention (parity mode)
  *                                                                   nsa/core/attention_kernels.py:273-388, 181-226
+ *   nsa_sel_attn_head_causal_parity  NSAAttention._sdpa_over_ranges (parity mode)   nsa/core/nsa_attention.py:1779-1855
  *   nsa_sel_attn_bwd           analytic backward / autograd of the masked SDPA
  *                                                                   nsa/kernels/triton_sel_kernel/__init__.py:125-231
  *   nsa_sel_scores             compute_pcmp_all + map_pcmp_to_pslc_batched + .sum(dim=3)
@@ -66,6 +67,13 @@ extern "C" {
 
 NSA_API int nsa_hip_abi_version(void);
 NSA_API const char *nsa_hip_last_error(void);
+/* Measurement / A-B switches (kernel form, staging, mapping).  Each switch is seeded once per process from the environment
+ * variable NSA_HIP_<NAME> and can be changed afterwards only through this call (nothing reads the environment on the launch
+ * path).  name: "SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS" (with or without the NSA_HIP_
+ * prefix); value -1 = automatic where the switch has an automatic setting.  Results never depend on a switch beyond the
+ * tolerances stated for the entry point. */
+NSA_API int nsa_hip_set_tuning(const char *name, int value);
+NSA_API int nsa_hip_get_tuning(const char *name, int *value);
 /* 0 if device `dev` is a gfx950 part; fills cu_count / total memory (host pointers, nullable). */
 NSA_API int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes);
 
@@ -100,6 +108,16 @@ NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const 
 NSA_API int nsa_sel_attn_first_key_parity(const void *V, const int32_t *ranges, void *O, int B, int S, int G, int h, int Dv,
                                   int S_kv, int n_ranges, int64_t v_stride_b, int64_t v_stride_g, int64_t v_stride_s,
                                   int dtype, void *stream);
+
+/* Opt-in PARITY MODE of NSAAttention._sdpa_over_ranges (nsa/core/nsa_attention.py:1779-1855), the reference's gather route of the
+ * decode and sequential-prefill paths (what NSA_FORCE_PARITY=1 leaves them on, :704-708, :830, :1687): the union of the clamped ranges
+ * is gathered in ascending token order and SDPA(is_causal=True) is called with the h heads in the query-length position, so head i
+ * attends the first i+1 gathered tokens (top-left aligned causal mask).  Rows without a token give zeros.  h <= 16.  Not the
+ * semantics of the selected branch -- kept so that outputs of the reference's forced-parity routing can be reproduced. */
+NSA_API int nsa_sel_attn_head_causal_parity(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, int B, int S, int G,
+                                    int h, int Dk, int Dv, int S_kv, int n_ranges, int64_t k_stride_b, int64_t k_stride_g,
+                                    int64_t k_stride_s, int64_t v_stride_b, int64_t v_stride_g, int64_t v_stride_s, int dtype,
+                                    float scale, void *stream);
 
 /* Backward.  dO like O; dQ like Q (dtype); dK/dV are fp32 [B,G,S_kv,D] contiguous, fully written by the callee.
  * O and lse come from the forward.

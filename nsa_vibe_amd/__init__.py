@@ -22,6 +22,7 @@ from .selection_attention import (  # noqa: F401
     hip_sel_available,
     select_and_attend,
     selection_attention_first_key_parity,
+    selection_attention_head_causal_parity,
     selection_attention_hip,
     selection_decode_step,
 )

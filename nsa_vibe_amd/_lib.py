@@ -46,9 +46,12 @@ SIGNATURES = {
     "nsa_hip_abi_version": (_i, []),
     "nsa_hip_last_error": (C.c_char_p, []),
     "nsa_hip_device_check": (_i, [_i, C.POINTER(_i), C.POINTER(_sz)]),
+    "nsa_hip_set_tuning": (_i, [C.c_char_p, _i]),
+    "nsa_hip_get_tuning": (_i, [C.c_char_p, C.POINTER(_i)]),
     "nsa_sel_attn_fwd_workspace": (_sz, [_i] * 8),
     "nsa_sel_attn_fwd": (_i, [_vp] * 6 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_sel_attn_first_key_parity": (_i, [_vp] * 3 + [_i] * 7 + [_i64] * 3 + [_i, _vp]),
+    "nsa_sel_attn_head_causal_parity": (_i, [_vp] * 5 + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),
     "nsa_sel_attn_bwd_workspace": (_sz, [_i] * 9),
     "nsa_sel_attn_bwd": (_i, [_vp] * 10 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_band_attn_fwd_workspace": (_sz, [_i] * 7),
@@ -116,6 +119,17 @@ def lib():
             raise ImportError("libnsa_sel_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+def set_tuning(name: str, value: int) -> None:
+    """process-wide A/B switch of the native library (include/nsa_sel_hip.h: nsa_hip_set_tuning); -1 = automatic"""
+    check(lib().nsa_hip_set_tuning(name.encode(), int(value)), "nsa_hip_set_tuning")
+
+
+def get_tuning(name: str) -> int:
+    v = _i(0)
+    check(lib().nsa_hip_get_tuning(name.encode(), C.byref(v)), "nsa_hip_get_tuning")
+    return v.value
 
 
 def last_error() -> str:

@@ -588,8 +588,7 @@ static int launch_band_t(const BandAttnParams &P0, hipStream_t st) {
     P.map_mode = (nbg % 8 == 0) ? 2 : 1;
     NSA_CHECK_ARG(nbg * W < ((int64_t)1 << 31), "band_attn: too many workgroups for one launch");
     const unsigned grid = (unsigned)(nbg * W);
-    const char *se = getenv("NSA_HIP_BAND_STAGE");  // A/B switch: 0 = register staging, 1 = LDS-DMA
-    const int stage = se ? atoi(se) : 1;  // measured: LDS-DMA 750 vs register staging 650 TFLOP/s (compressed branch, 64k)
+    const int stage = tuning(TUNE_BAND_STAGE);  // A/B switch: 0 = register staging, 1 = LDS-DMA  // measured: LDS-DMA 750 vs register staging 650 TFLOP/s (compressed branch, 64k)
     constexpr int NTW = D == 64 ? 3 : 2;
     bool done = false;
     if constexpr (D == 64) {

@@ -4,7 +4,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+#include <strings.h>
+
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "nsa_common.hpp"
@@ -26,6 +31,34 @@ void set_error(const char *fmt, ...) {
 int hip_fail(hipError_t e, const char *what) {
     set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
     return NSA_ERR_HIP;
+}
+
+// ---- tuning switches -------------------------------------------------------------------------
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, 0, -1};
+static std::atomic<int> g_tune[TUNE_COUNT];
+static std::once_flag g_tune_once;
+
+static void tune_init() {
+    for (int i = 0; i < TUNE_COUNT; ++i) {
+        char name[64];
+        snprintf(name, sizeof(name), "NSA_HIP_%s", g_tune_names[i]);
+        const char *e = getenv(name);
+        g_tune[i].store(e ? atoi(e) : g_tune_defaults[i], std::memory_order_relaxed);
+    }
+}
+
+int tuning(Tune t) {
+    std::call_once(g_tune_once, tune_init);
+    return g_tune[t].load(std::memory_order_relaxed);
+}
+
+static int tune_index(const char *name) {
+    if (!name) return -1;
+    if (strncmp(name, "NSA_HIP_", 8) == 0) name += 8;
+    for (int i = 0; i < TUNE_COUNT; ++i)
+        if (strcasecmp(name, g_tune_names[i]) == 0) return i;
+    return -1;
 }
 
 // implemented in the kernel translation units
@@ -63,6 +96,21 @@ extern "C" {
 int nsa_hip_abi_version(void) { return NSA_HIP_ABI_VERSION; }
 
 const char *nsa_hip_last_error(void) { return g_err; }
+
+int nsa_hip_set_tuning(const char *name, int value) {
+    const int i = tune_index(name);
+    NSA_CHECK_ARG(i >= 0, "unknown tuning switch '%s'", name ? name : "(null)");
+    std::call_once(g_tune_once, tune_init);
+    g_tune[i].store(value, std::memory_order_relaxed);
+    return NSA_OK;
+}
+
+int nsa_hip_get_tuning(const char *name, int *value) {
+    const int i = tune_index(name);
+    NSA_CHECK_ARG(i >= 0 && value, "unknown tuning switch '%s'", name ? name : "(null)");
+    *value = tuning((Tune)i);
+    return NSA_OK;
+}
 
 int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes) {
     int n = 0;
@@ -164,6 +212,29 @@ int nsa_sel_attn_first_key_parity(const void *V, const int32_t *ranges, void *O,
         return NSA_OK;
     }
     return launch_sel_first_key(V, ranges, O, R, S, G, h, Dv, n_ranges, S_kv, vsb, vsg, vss, esz, (hipStream_t)stream);
+}
+
+int nsa_sel_attn_head_causal_parity(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, int B, int S, int G, int h,
+                                    int Dk, int Dv, int S_kv, int n_ranges, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg,
+                                    int64_t vss, int dtype, float scale, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_attn_head_causal_parity: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && Dk >= 1 && Dv >= 1 && S_kv >= 0 && n_ranges >= 0,
+                  "sel_attn_head_causal_parity: negative size");
+    NSA_CHECK_ARG(n_ranges <= 64, "sel_attn_head_causal_parity: at most 64 ranges per row are supported (got %d)", n_ranges);
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0) return NSA_OK;
+    NSA_CHECK_ARG(Q && O && (ranges || n_ranges == 0) && ((K && V) || S_kv == 0), "sel_attn_head_causal_parity: null pointer");
+    const int esz = dtype == NSA_DT_F32 ? 4 : 2;
+    if (S_kv == 0 || n_ranges == 0) {
+        NSA_HIP_TRY(hipMemsetAsync(O, 0, (size_t)R * h * Dv * esz, (hipStream_t)stream));
+        return NSA_OK;
+    }
+    SelAttnParams P{};
+    P.Q = Q, P.K = K, P.V = V, P.ranges = ranges, P.O = O, P.lse = nullptr;
+    P.R = R, P.S = S, P.G = G, P.h = h, P.Dk = Dk, P.Dv = Dv, P.S_kv = S_kv, P.n = n_ranges;
+    P.ksb = ksb, P.ksg = ksg, P.kss = kss, P.vsb = vsb, P.vsg = vsg, P.vss = vss;
+    P.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    return launch_sel_head_causal(P, dtype, (hipStream_t)stream);
 }
 
 size_t nsa_sel_attn_bwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int dtype, int variant) {

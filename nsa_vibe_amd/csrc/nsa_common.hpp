@@ -31,6 +31,20 @@ int hip_fail(hipError_t e, const char *what);
         if (_e != hipSuccess) return ::nsa::hip_fail(_e, name " launch");   \
     } while (0)
 
+// ---- measurement / A-B switches (host) -----------------------------------------------------
+// Process-wide integer switches, seeded ONCE from the environment (NSA_HIP_<NAME>) when the library is first asked and
+// changed afterwards only through nsa_hip_set_tuning (include/nsa_sel_hip.h): no getenv on the launch path.
+enum Tune {
+    TUNE_SEL_ROWS = 0,      // NSA_HIP_SEL_ROWS: selection forward/backward form, -1 auto, 0 one row per wave, 1 pairs, 3 48-slot tiles
+    TUNE_ATTN_MAP,          // NSA_HIP_ATTN_MAP: one-row kernel workgroup mapping, -1 auto
+    TUNE_ATTN_STAGE,        // NSA_HIP_ATTN_STAGE: 0 register staging, 1 LDS-DMA (default)
+    TUNE_BAND_STAGE,        // NSA_HIP_BAND_STAGE: same for the band kernel
+    TUNE_DECODE_UNFUSED,    // NSA_HIP_DECODE_UNFUSED: 1 = three-kernel decode scorer route
+    TUNE_SEL_BLOCKS,        // NSA_HIP_SEL_BLOCKS: 64-key block form of the selection forward, -1 auto, 0 off, N = row pairs per wave
+    TUNE_COUNT
+};
+int tuning(Tune t);
+
 // ---- vector types ----------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -84,7 +84,7 @@ int nsa_cmp_pool_append(const nsa_layer_desc *L, const nsa_kv_desc *kv, int j0, 
     P.nbg = kv->B * L->G; P.S_max = kv->S_max; P.n_cmp_max = kv->n_cmp_max; P.Dk = L->Dk; P.Dv = L->Dv; P.l = L->l; P.d = L->d;
     P.j0 = j0; P.j1 = j1;
     P.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
-    P.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    P.inv_scale = 1.0f;  // the reference pools apply_rope(K_raw, pos) WITHOUT the NSA_ROPE_SCALE position scaling (compress_pool.py:20)
     return launch_cmp_pool(P, L->dtype, (hipStream_t)stream);
 }
 
@@ -128,7 +128,7 @@ int nsa_cmp_pool_bwd(const nsa_layer_desc *L, int B, int S, int n_cmp, const voi
     CmpPoolParams P{};
     P.nbg = B * L->G; P.Dk = L->Dk; P.Dv = L->Dv; P.l = L->l; P.d = L->d;
     P.rope_base = L->rope_base > 0.f ? L->rope_base : 10000.0f;
-    P.inv_scale = 1.0f / (L->rope_scale > 0.f ? L->rope_scale : 1.0f);
+    P.inv_scale = 1.0f;  // as the forward: no position scaling inside the pooled keys (compress_pool.py:20)
     return launch_cmp_pool_bwd(P, dK_cmp, dV_cmp, dK_raw, dV_raw, S, n_cmp, L->dtype, (hipStream_t)stream);
 }
 

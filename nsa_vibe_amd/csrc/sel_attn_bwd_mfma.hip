@@ -893,8 +893,7 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
     if (!P.skip_delta_dq) {
         // rows of one wave share the K/V tile images when 16/h >= 2 rows fit the MFMA columns (NSA_HIP_SEL_ROWS=0: one row per wave)
         int tpw = 16 / P.h;
-        if (const char *e = getenv("NSA_HIP_SEL_ROWS"))
-            if (atoi(e) == 0) tpw = 1;
+        if (tuning(TUNE_SEL_ROWS) == 0) tpw = 1;
         const int nw = ((P.S_kv + 31) / 32 + 31) / 32;
         if (tpw >= 2 && P.S >= 2 * tpw && P.n >= 1 && P.n <= 64 && nw <= 128) {
             const int rg_ints = (2 * tpw * P.n + 3) & ~3, bm_ints = (2 * tpw * nw + 16 + 3) & ~3;

@@ -362,5 +362,80 @@ int launch_sel_first_key(const void *V, const int32_t *ranges, void *O, int64_t 
     return NSA_OK;
 }
 
+// ---- parity mode of NSAAttention._sdpa_over_ranges (nsa_attention.py:1779-1855): the reference's decode / sequential-prefill gather route ----
+// It gathers the union of the clamped ranges in ascending token order and calls SDPA(is_causal=True) with the h heads of the group in
+// the QUERY-LENGTH position (q is [1,h,Dk]), so the top-left aligned causal mask lets head i see the first i+1 gathered tokens only.
+// One wave per row; fp32 math; a row without tokens gives zeros (the reference feeds one zero key/value).
+constexpr int HC_MAX = 16;  // heads (= visible tokens) supported
+
+template <typename T>
+__global__ __launch_bounds__(256) void sel_head_causal_kernel(SelAttnParams P) {
+    __shared__ int s_seg[4][SEG_INTS];
+    __shared__ int s_tok[4][HC_MAX];
+    __shared__ float s_p[4][HC_MAX * HC_MAX];
+    const int lane = lane_id();
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= P.R) return;
+    const int Dk = P.Dk, Dv = P.Dv, h = P.h;
+    int *seg = s_seg[wave];
+    int *tok = s_tok[wave];
+    float *pp = s_p[wave];
+    const int g = (int)(row % P.G);
+    const int b = (int)(row / ((int64_t)P.G * P.S));
+    const T *Kb = (const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg;
+    const T *Vb = (const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg;
+    const T *Qr = (const T *)P.Q + row * (int64_t)h * Dk;
+    T *Or = (T *)P.O + row * (int64_t)h * Dv;
+    int nseg;
+    const int L = normalise_ranges(P.ranges + row * (int64_t)P.n * 2, P.n, P.S_kv, seg, &nseg);
+    const int Lh = min(L, h);  // tokens any head can see
+    if (Lh == 0) {
+        for (int i = lane; i < h * Dv; i += 64) Or[i] = Elt<T>::from_f(0.f);
+        return;
+    }
+    if (lane < Lh) tok[lane] = token_at(seg, nseg, lane);
+    wave_lds_fence();
+    // scaled logits of the visible (head i, token j <= i) pairs
+    for (int p = lane; p < h * Lh; p += 64) {
+        const int i = p / Lh, j = p - i * Lh;
+        float s = -INFINITY;
+        if (j <= i) {
+            const T *q = Qr + (int64_t)i * Dk;
+            const T *k = Kb + (int64_t)tok[j] * P.kss;
+            s = 0.f;
+            for (int d = 0; d < Dk; ++d) s = fmaf(Elt<T>::to_f(q[d]), Elt<T>::to_f(k[d]), s);
+            s *= P.scale;
+        }
+        pp[i * HC_MAX + j] = s;
+    }
+    wave_lds_fence();
+    if (lane < h) {  // softmax of head `lane` over its visible tokens
+        const int nv = min(lane + 1, Lh);
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < nv; ++j) m = fmaxf(m, pp[lane * HC_MAX + j]);
+        for (int j = 0; j < nv; ++j) l += __expf(pp[lane * HC_MAX + j] - m);
+        for (int j = 0; j < Lh; ++j) pp[lane * HC_MAX + j] = j < nv ? __expf(pp[lane * HC_MAX + j] - m) / l : 0.f;
+    }
+    wave_lds_fence();
+    for (int o = lane; o < h * Dv; o += 64) {
+        const int i = o / Dv, d = o - i * Dv;
+        float acc = 0.f;
+        for (int j = 0; j < Lh; ++j) acc = fmaf(pp[i * HC_MAX + j], Elt<T>::to_f(Vb[(int64_t)tok[j] * P.vss + d]), acc);
+        Or[o] = Elt<T>::from_f(acc);
+    }
+}
+
+int launch_sel_head_causal(const SelAttnParams &P, int dtype, hipStream_t st) {
+    NSA_CHECK_ARG(P.h <= HC_MAX, "sel_attn_head_causal_parity: at most %d heads per group (got %d)", HC_MAX, P.h);
+    const unsigned grid = (unsigned)((P.R + 3) / 4);
+    switch (dtype) {
+        case NSA_DT_F32: hipLaunchKernelGGL(sel_head_causal_kernel<float>, dim3(grid), dim3(256), 0, st, P); break;
+        case NSA_DT_BF16: hipLaunchKernelGGL(sel_head_causal_kernel<__bf16>, dim3(grid), dim3(256), 0, st, P); break;
+        default: hipLaunchKernelGGL(sel_head_causal_kernel<_Float16>, dim3(grid), dim3(256), 0, st, P); break;
+    }
+    NSA_LAUNCH_CHECK("sel_head_causal");
+    return NSA_OK;
+}
 
 }  // namespace nsa

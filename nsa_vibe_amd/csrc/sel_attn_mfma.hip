@@ -423,16 +423,14 @@ static int launch_mfma_t(const SelAttnParams &P0, hipStream_t st) {
             grid = (unsigned)(nbg * W);
         }
     }
-    if (const char *e = getenv("NSA_HIP_ATTN_MAP")) {  // A/B switch for measurements: force a mapping
-        const int m = atoi(e);
+    if (const int m = tuning(TUNE_ATTN_MAP); m >= 0) {  // A/B switch for measurements: force a mapping
         if (!split && m == 0) {
             P.map_mode = 0;
             grid = (unsigned)((waves + 3) / 4);
         }
         if (!split && m == 1 && P.map_mode == 2) P.map_mode = 1;
     }
-    const char *se = getenv("NSA_HIP_ATTN_STAGE");  // A/B switch: 0 = register staging, 1 = LDS-DMA
-    const int stage = se ? atoi(se) : 1;  // default: LDS-DMA (measured 3-5 % faster than register staging at S<=16k)
+    const int stage = tuning(TUNE_ATTN_STAGE);  // A/B switch: 0 = register staging, 1 = LDS-DMA  // default: LDS-DMA (measured 3-5 % faster than register staging at S<=16k)
     void (*k)(SelAttnParams, SelectParams, int) = nullptr;
     if (split && stage == 1) k = sel_attn_fwd_mfma_kernel<T, D, true, 1>;
     else if (split) k = sel_attn_fwd_mfma_kernel<T, D, true, 0>;

@@ -78,6 +78,7 @@ int launch_band_attn_fwd_generic(const BandAttnParams &P, int dtype, hipStream_t
 
 int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);
 int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_t st);
+int launch_sel_head_causal(const SelAttnParams &P, int dtype, hipStream_t st);  // parity mode of _sdpa_over_ranges
 // returns NSA_ERR_INVALID (without setting an error) when the shape is not covered
 bool sel_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
 int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st);

@@ -459,8 +459,7 @@ int sel_attn_rows_tpw(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, 
     *nt = 1;
     if (!(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) || Dk != Dv || (Dk != 64 && Dk != 128) || h < 1 || h > 16) return 0;
     if (n < 1 || n > 64 || S_kv < 1 || S_kv > 131072) return 0;
-    int mode = -1;  // NSA_HIP_SEL_ROWS: 0 = off, 1 = pairs (NT 1), 3 = query tiles (NT 3); unset = automatic
-    if (const char *e = getenv("NSA_HIP_SEL_ROWS")) mode = atoi(e);
+    const int mode = tuning(TUNE_SEL_ROWS);  // 0 = off, 1 = pairs (NT 1), 3 = query tiles (NT 3); -1 = automatic
     if (mode == 0) return 0;
     int want_nt = 1;
     if (Dk == 64 && (mode == 3 || (mode < 0 && S_kv <= 1536 && R >= 16384 && h >= 3))) want_nt = 3;

@@ -108,6 +108,7 @@ class LlamaBlockNSA(nn.Module):
         block appends to that cache (prefill=True for the first S tokens, prefill=False for one decode token)."""
         if kv is None:
             kv = self.attn.new_kv(x.shape[0], x.shape[1], x.device, x.dtype)
+        self.attn._check_kv(x, kv)  # the native calls below walk kv.B sequences of the cache's dtype: it must match x
         if not prefill and x.shape[1] == 1 and self.attn._native_ok(x) and self.norm1.weight.dtype == x.dtype:
             y = self._decode_native(x, kv)
             return (y, kv) if return_kv else y
@@ -245,7 +246,9 @@ class TinyLM(nn.Module):
 
         a0, kv0 = self.blocks[0].attn, caches[0]
         t, B, dev = kv0.t, tokens.shape[0], tokens.device
-        for kv in caches:
+        probe = torch.empty((B, 1, 0), dtype=self.embed.weight.dtype, device=dev)
+        for blk, kv in zip(self.blocks, caches):
+            blk.attn._check_kv(probe, kv)
             kv.ensure_capacity(t + 1)
         if kv0.meta.S_sel == 0:
             meta = kv0.ensure_meta(max(t + 1, a0.l_sel))

@@ -29,7 +29,13 @@ import torch.nn.functional as F
 from . import _lib
 from .band_attention import batched_causal_attention_compressed, sliding_window_attention
 from .kv_cache import NSA_KV
-from .selection_attention import select_and_attend, selection_attention_hip, selection_decode_step
+from .selection_attention import (
+    select_and_attend,
+    selection_attention_first_key_parity,
+    selection_attention_head_causal_parity,
+    selection_attention_hip,
+    selection_decode_step,
+)
 from .selection_scorer import _DT, _stream, select_topn_ranges_batched, select_topn_ranges_rows, selection_scores, workspace
 
 
@@ -254,6 +260,12 @@ class NSAAttention(nn.Module):
         self.gate = GateMLP(d_k, gate_hidden)
         self._last_gates: Optional[torch.Tensor] = None
         self._last_ranges: Optional[torch.Tensor] = None
+        # Routing contract of the reference (nsa_attention.py:300-332 flag cache read at construction, :704-708 / :1205-1211):
+        # NSA_FORCE_PARITY=1 disables every fast selection route, which leaves the reference on its gather executors -- batched
+        # prefill on grouped_selection_attention (first gathered key, attention_kernels.py:181-226), decode and sequential prefill
+        # on _sdpa_over_ranges (head i sees the first i+1 gathered keys, :1779-1855).  Here that flag routes the selected branch
+        # to the two parity-mode executors that reproduce those outputs; everything else stays on the native kernels.
+        self._force_parity = os.getenv("NSA_FORCE_PARITY", "0").lower() in ("1", "true", "yes")
         self._fallback_counters = {k: 0 for k in ("selection_triton_fails", "selection_cuda_fails", "selection_hip_fails",
                                                   "selection_pack_fails", "selection_mask_fails", "compressed_fa2_fails",
                                                   "sliding_fa2_fails", "total_fallbacks")}
@@ -295,13 +307,15 @@ class NSAAttention(nn.Module):
 
     def _native_ok(self, x: torch.Tensor) -> bool:
         """the fused kernels cover inference (no autograd graph) on the GPU; training keeps the differentiable eager ops"""
+        if self._force_parity:
+            return False  # the one-call layer fuses the masked-semantics executor; parity mode composes the layer from its stages
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
         return x.is_cuda and x.dtype in _DT and self.W_Q.weight.dtype == x.dtype and self.gate.fc1.out_features <= 64
 
     def _train_native_ok(self, x: torch.Tensor) -> bool:
         """training (autograd) on the GPU: the layer kernels run as differentiable ops (native backward kernels)"""
-        return (torch.is_grad_enabled() and x.is_cuda and x.dtype in _DT and self.W_Q.weight.dtype == x.dtype
+        return (torch.is_grad_enabled() and x.is_cuda and x.dtype in _DT and self.W_Q.weight.dtype == x.dtype and not self._force_parity
                 and self.gate.fc1.out_features <= 64 and os.getenv("NSA_HIP_EAGER_TRAIN", "0") != "1")
 
     def _layer_desc(self):
@@ -352,13 +366,34 @@ class NSAAttention(nn.Module):
         return self.out(O.reshape(B, S, self.n_heads * self.d_v))
 
     # ---- forward ---------------------------------------------------------------------------
+    def _check_kv(self, x: torch.Tensor, kv: NSA_KV) -> None:
+        """The C ABI sees raw pointers: the kernels walk kv.B sequences of the cache's dtype, so a cache built for another batch
+        size, dtype or device would be read and written out of bounds.  Refuse it here."""
+        buf = kv._K_sel
+        if x.shape[0] != kv.B or buf.dtype != x.dtype or buf.device != x.device:
+            raise RuntimeError(f"NSA_KV does not match the input: cache B={kv.B} {buf.dtype} on {buf.device}, "
+                               f"x B={x.shape[0]} {x.dtype} on {x.device}")
+        if (kv.G, kv.d_k, kv.d_v) != (self.n_kv_groups, self.d_k, self.d_v):
+            raise RuntimeError(f"NSA_KV geometry (G={kv.G}, d_k={kv.d_k}, d_v={kv.d_v}) does not match the module "
+                               f"(G={self.n_kv_groups}, d_k={self.d_k}, d_v={self.d_v})")
+
     def forward(self, x: torch.Tensor, kv: NSA_KV, *, prefill: bool):
         assert x.dim() == 3, "x must be [B,S,dim]"
         if prefill:
             assert x.shape[1] > 0, f"Prefill mode requires S > 0, got S={x.shape[1]}"
-            return self._prefill(x, kv)
-        assert x.shape[1] == 1, f"Decode mode requires S=1 (single token), got S={x.shape[1]}."
-        return self._decode(x, kv)
+        else:
+            assert x.shape[1] == 1, f"Decode mode requires S=1 (single token), got S={x.shape[1]}."
+        self._check_kv(x, kv)
+        try:
+            return self._prefill(x, kv) if prefill else self._decode(x, kv)
+        except RuntimeError as e:
+            # the reference's router counts a failed native executor and falls back to a safer torch executor
+            # (nsa_attention.py:764-782).  There is no other executor behind this one by design (a silent CPU / eager fallback would void
+            # every parity claim), so the failure is counted where the reference counts it and then raised.
+            self._fallback_counters["selection_hip_fails"] += 1
+            self._fallback_counters["total_fallbacks"] += 1
+            self._last_error = str(e)
+            raise
 
     def _prefill(self, x: torch.Tensor, kv: NSA_KV):
         B, S, _ = x.shape
@@ -383,7 +418,11 @@ class NSAAttention(nn.Module):
             ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
         else:
             ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
-        O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
+        if self._force_parity:  # reference gather routes: batched -> first gathered key, sequential -> _sdpa_over_ranges
+            parity = selection_attention_first_key_parity if self.selector == "batched" else selection_attention_head_causal_parity
+            O_sel = parity(Qc, kv.K_sel, kv.V_sel, ranges)
+        else:
+            O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
         self._last_ranges = ranges
         # ---- compressed + sliding branches (HIP band kernel)
         O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, scale=scale)
@@ -506,6 +545,8 @@ class NSAAttention(nn.Module):
         scale = 1.0 / math.sqrt(self.d_k)
         Qc = Q.contiguous()
         O_sel, ranges = selection_decode_step(Qc, kv.K_cmp, kv.K_sel, kv.V_sel, kv.meta, self.n_sel, t, scale=scale)
+        if self._force_parity:  # the reference's decode gather route (_sdpa_over_ranges, nsa_attention.py:830)
+            O_sel = selection_attention_head_causal_parity(Qc, kv.K_sel, kv.V_sel, ranges.unsqueeze(1))
         self._last_ranges = ranges
         # the query sits at position t: window = the last w cached tokens, compressed = every token emitted so far
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S_raw], kv._V_win[:, :, :S_raw], self.w, t0=t, scale=scale)

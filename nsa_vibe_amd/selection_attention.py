@@ -137,6 +137,30 @@ def selection_attention_first_key_parity(Q: torch.Tensor, K: torch.Tensor, V: to
     return O
 
 
+def selection_attention_head_causal_parity(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, ranges: torch.Tensor, *,
+                                           scale: Optional[float] = None) -> torch.Tensor:
+    """PARITY MODE, opt-in: what NSAAttention._sdpa_over_ranges returns (nsa/core/nsa_attention.py:1779-1855), the gather route the
+    reference's decode and sequential prefill fall to (and the only one left under NSA_FORCE_PARITY=1).  It hands SDPA the h heads of a
+    group as the query LENGTH with is_causal=True, so head i attends the first i+1 tokens of the gathered union (ascending token
+    order); rows without a token give zeros.  Executor signature ([B,S,G,...] tensors); inference only."""
+    dev = _need_gpu(Q, K, V)
+    if torch.is_grad_enabled() and (Q.requires_grad or K.requires_grad or V.requires_grad):
+        raise RuntimeError("selection_attention_head_causal_parity is an inference-only parity mode")
+    if not (Q.dtype == K.dtype == V.dtype) or Q.dtype not in _DT:
+        raise RuntimeError("selection_attention_head_causal_parity: Q/K/V must share a dtype in fp32/bf16/fp16")
+    B, S, G, h, Dk = Q.shape
+    S_kv, Dv = V.shape[2], V.shape[3]
+    Qc, Kk, Vv, rg = Q.contiguous(), _prep_kv(K), _prep_kv(V), _prep_ranges(ranges)
+    if rg.shape[:3] != (B, S, G) or Kk.shape[:3] != (B, G, S_kv):
+        raise RuntimeError("selection_attention_head_causal_parity: inconsistent shapes")
+    O = torch.empty((B, S, G, h, Dv), dtype=V.dtype, device=dev)
+    rc = _lib.lib().nsa_sel_attn_head_causal_parity(Qc.data_ptr(), Kk.data_ptr(), Vv.data_ptr(), rg.data_ptr(), O.data_ptr(), B, S, G, h, Dk,
+                                                    Dv, S_kv, rg.shape[3], Kk.stride(0), Kk.stride(1), Kk.stride(2), Vv.stride(0),
+                                                    Vv.stride(1), Vv.stride(2), _DT[Q.dtype], float(scale) if scale else 0.0, _stream(dev))
+    _lib.check(rc, "nsa_sel_attn_head_causal_parity")
+    return O
+
+
 def selection_decode_step(Q: torch.Tensor, K_cmp: torch.Tensor, K: torch.Tensor, V: torch.Tensor, meta, n_top: int, t_token: int,
                           *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
                           ranges_out: Optional[torch.Tensor] = None):

@@ -267,6 +267,35 @@ def sel_attention_first_key_parity(Q, V, ranges) -> np.ndarray:
     return O
 
 
+def sel_attention_head_causal_parity(Q, K, V, ranges, scale=None) -> np.ndarray:
+    """PARITY MODE of NSAAttention._sdpa_over_ranges (nsa_attention.py:1779-1855): tokens of the union of the clamped ranges in ascending
+    order; SDPA(is_causal=True) sees the h heads as query positions, so head i attends the first i+1 gathered tokens; a row without a
+    token gives zeros (the reference feeds a single zero key / value).  Pure numpy (small cases)."""
+    Q, K, V, r = (np.asarray(x) for x in (Q, K, V, ranges))
+    B, S, G, h, Dk = Q.shape
+    S_kv = K.shape[2]
+    sc = float(scale) if scale else 1.0 / np.sqrt(Dk)
+    O = np.zeros((B, S, G, h, V.shape[3]), dtype=np.float32)
+    for b in range(B):
+        for t in range(S):
+            for g in range(G):
+                m = np.zeros(S_kv, dtype=bool)
+                for s0, e0 in r[b, t, g]:
+                    s0, e0 = min(max(int(s0), 0), S_kv), min(max(int(e0), 0), S_kv)
+                    if e0 > s0:
+                        m[s0:e0] = True
+                idx = np.nonzero(m)[0][:h]
+                if idx.size == 0:
+                    continue
+                k, v = K[b, g, idx].astype(np.float32), V[b, g, idx].astype(np.float32)
+                for i in range(h):
+                    nv = min(i + 1, idx.size)
+                    s = (Q[b, t, g, i].astype(np.float32) @ k[:nv].T) * sc
+                    p = np.exp(s - s.max())
+                    O[b, t, g, i] = (p / p.sum()) @ v[:nv]
+    return O.astype(V.dtype) if V.dtype == np.float32 else O
+
+
 def normalise_ranges(r: np.ndarray) -> list:
     """Drop e<=s entries (SURVEY 7 hard part (c)); returns nested lists of (s,e) per row."""
     r = np.asarray(r)

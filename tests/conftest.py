@@ -28,6 +28,23 @@ def _seed():
     yield
 
 
+@pytest.fixture
+def tune():
+    """set an A/B switch of the native library for one test (nsa_hip_set_tuning); every switch touched is restored afterwards"""
+    from nsa_vibe_amd import _lib
+
+    saved = {}
+
+    def _set(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_tuning(name)
+        _lib.set_tuning(name, int(value))
+
+    yield _set
+    for name, value in saved.items():
+        _lib.set_tuning(name, value)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

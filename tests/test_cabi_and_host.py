@@ -278,3 +278,91 @@ def test_eq9_slow_path_matches_the_oracle_mapping(nv, orc):
     assert short.shape[-1] == meta.S_sel and not short[..., 4:].any()
     ok, info = nv.verify_mapping_equivalence(torch.from_numpy(p), meta)
     assert ok and info["status"] == "skipped"
+
+
+def test_routing_contract_counts_a_failed_native_call_and_raises(monkeypatch):
+    """counterpart of nsa/tests/test_cuda_loader_fallback.py:6-38 for the routing contract of nsa_attention.py:764-782: a native call
+    that fails bumps selection_hip_fails / total_fallbacks; there is no other executor to fall back to, so the error is raised
+    (CPU tensors make every native entry refuse)"""
+    import torch
+
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    m = NSAAttention(64, 4, 2, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16).eval()
+    x = torch.randn(1, 24, 64)
+    with torch.no_grad():
+        for i in range(2):
+            with pytest.raises(RuntimeError, match="no CPU fallback"):
+                m(x, m.new_kv(1, 32, "cpu", torch.float32), prefill=True)
+            c = m.get_fallback_counters()
+            assert c["selection_hip_fails"] == i + 1 and c["total_fallbacks"] == i + 1
+    assert m.reset_fallback_counters()["selection_hip_fails"] == 2 and m.get_fallback_counters()["total_fallbacks"] == 0
+
+
+def test_routing_contract_failing_library_call(monkeypatch):
+    """a library whose entry point returns an error status (the BadExt of test_cuda_loader_fallback.py:9-22): RuntimeError with the
+    library's message + counter, nothing is silently rerouted"""
+    import torch
+
+    import nsa_vibe_amd.selection_scorer as sc
+    from nsa_vibe_amd import _lib
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    def bad_scores(*a, **k):
+        _lib.check(-2, "nsa_sel_scores (synthetic forward failure)")
+
+    monkeypatch.setattr("nsa_vibe_amd.nsa_attention.selection_scores", bad_scores)
+    monkeypatch.setattr(sc, "_need_gpu", lambda *t: t[0].device)  # let CPU tensors reach the (failing) native call
+    m = NSAAttention(64, 4, 2, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="synthetic forward failure"):
+        m(torch.randn(1, 24, 64), m.new_kv(1, 32, "cpu", torch.float32), prefill=True)
+    assert m.get_fallback_counters()["selection_hip_fails"] == 1
+
+
+def test_force_parity_flag_is_read_at_construction(monkeypatch):
+    """NSA_FORCE_PARITY (nsa_attention.py:300-332 flag cache, :704-708): read once when the module is built"""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    monkeypatch.setenv("NSA_FORCE_PARITY", "1")
+    m = NSAAttention(64, 4, 2, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16)
+    monkeypatch.setenv("NSA_FORCE_PARITY", "0")
+    m2 = NSAAttention(64, 4, 2, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16)
+    assert m._force_parity and not m2._force_parity
+
+
+def test_kv_cache_must_match_the_input():
+    """the native calls walk kv.B sequences of the cache's dtype: a cache built for another batch / dtype / geometry is refused
+    before any kernel can run out of bounds"""
+    import torch
+
+    from nsa_vibe_amd.llama_block_nsa import LlamaBlockNSA
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    m = NSAAttention(64, 4, 2, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16).eval()
+    x = torch.randn(2, 24, 64)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="does not match the input"):
+            m(x, m.new_kv(3, 32, "cpu", torch.float32), prefill=True)  # larger batch in the cache
+        with pytest.raises(RuntimeError, match="does not match the input"):
+            m(x, m.new_kv(2, 32, "cpu", torch.bfloat16), prefill=True)  # other dtype
+        other = NSAAttention(64, 4, 1, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16)
+        with pytest.raises(RuntimeError, match="geometry"):
+            m(x, other.new_kv(2, 32, "cpu", torch.float32), prefill=True)
+        blk = LlamaBlockNSA(64, 4, 2, 16, 16, l=8, d=4, l_sel=16, n_sel=4, w=16).eval()
+        with pytest.raises(RuntimeError, match="does not match the input"):
+            blk(x[:, :1], blk.attn.new_kv(5, 32, "cpu", torch.float32), prefill=False)
+    assert m.get_fallback_counters()["total_fallbacks"] == 0  # refused before any native call: not a kernel failure
+
+
+def test_tuning_switches_roundtrip():
+    """nsa_hip_set_tuning / nsa_hip_get_tuning: process-wide A/B switches (nothing reads the environment per launch)"""
+    from nsa_vibe_amd import _lib
+
+    old = _lib.get_tuning("SEL_ROWS")
+    try:
+        _lib.set_tuning("NSA_HIP_SEL_ROWS", 3)
+        assert _lib.get_tuning("sel_rows") == 3
+    finally:
+        _lib.set_tuning("SEL_ROWS", old)
+    with pytest.raises(RuntimeError, match="unknown tuning switch"):
+        _lib.set_tuning("NO_SUCH_SWITCH", 1)

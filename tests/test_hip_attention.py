@@ -359,10 +359,10 @@ def test_first_key_parity_mode_matches_reference_default_executors(nv, orc, name
 # ---- the query-tile forward kernel (sel_attn_rows_mfma.hip): several rows per wave sharing K/V tiles -------------------------
 @pytest.mark.parametrize("mode", ["1", "3"])  # 1 = 16/h rows per wave ("pairs" at h = 6), 3 = 48/h rows
 @pytest.mark.parametrize("h,D", [(3, 64), (4, 64), (5, 64), (6, 64), (8, 64), (16, 64), (2, 128), (4, 128), (8, 128)])
-def test_query_tile_kernel_against_oracle(nv, orc, mode, h, D, monkeypatch):
+def test_query_tile_kernel_against_oracle(nv, orc, mode, h, D, tune):
     """rows of one wave with DIFFERENT selections: unaligned, overlapping and duplicate ranges (partially covered tiles), an empty
     row, a row covering everything, a key range that ends in the last (partial) tile of K/V, odd S (last wave short)"""
-    monkeypatch.setenv("NSA_HIP_SEL_ROWS", mode)
+    tune("SEL_ROWS", mode)
     rng = np.random.default_rng([h, D, int(mode)])
     B, S, G, n, S_kv = 2, 37, 2, 9, 333  # S_kv not a multiple of 32
     Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
@@ -380,7 +380,7 @@ def test_query_tile_kernel_against_oracle(nv, orc, mode, h, D, monkeypatch):
         run_case(nv, orc, Q, K, V, rg, dtype, variant=2)
 
 
-def test_query_tile_kernel_long_context_second_bitmap_word_group(nv, monkeypatch):
+def test_query_tile_kernel_long_context_second_bitmap_word_group(nv, tune):
     """S_kv > 65536: the tile schedule spans more than 64 bitmap words (second register of the schedule); against the generic kernel"""
     rng = np.random.default_rng(123)
     B, S, G, h, D, n, S_kv = 1, 24, 2, 6, 64, 16, 100000
@@ -394,14 +394,14 @@ def test_query_tile_kernel_long_context_second_bitmap_word_group(nv, monkeypatch
     rg[0, 3, 1, 2] = (65500, 65600)  # straddles the word-group boundary (tile 2047 | 2048)
     want = nv.selection_attention_hip(Q, K, V, dev(rg), variant=1).float()
     for mode in ("1", "3"):
-        monkeypatch.setenv("NSA_HIP_SEL_ROWS", mode)
+        tune("SEL_ROWS", mode)
         got = nv.selection_attention_hip(Q, K, V, dev(rg), variant=2, return_lse=True)
         assert (got[0].float() - want).abs().max().item() <= 1e-2
         assert torch.isfinite(got[1]).all()
 
 
 @pytest.mark.parametrize("mode", ["sequential", "batched"])
-def test_query_tile_kernel_equals_one_row_kernel_on_selector_output(nv, mode, monkeypatch):
+def test_query_tile_kernel_equals_one_row_kernel_on_selector_output(nv, mode, tune):
     """m7c geometry, ranges from the real selector (fused in the launch): all three forward kernels agree, and the fused launch
     writes the same ranges whichever kernel hosts the selector"""
     torch.manual_seed(3)
@@ -413,14 +413,14 @@ def test_query_tile_kernel_equals_one_row_kernel_on_selector_output(nv, mode, mo
     p = torch.rand(B, S, G, meta.S_sel, device="cuda")
     outs = {}
     for m in ("0", "1", "3"):
-        monkeypatch.setenv("NSA_HIP_SEL_ROWS", m)
+        tune("SEL_ROWS", m)
         outs[m] = nv.select_and_attend(p, Q, K, V, meta, 16, mode=mode, scale=0.125)
     for m in ("1", "3"):
         assert torch.equal(outs[m][0], outs["0"][0])
         assert (outs[m][1].float() - outs["0"][1].float()).abs().max().item() <= 2e-2
 
 
-def test_backward_query_tile_dq_long_context_and_kernel_switch(nv, monkeypatch):
+def test_backward_query_tile_dq_long_context_and_kernel_switch(nv, tune):
     """dQ of the query-tile kernel (rows of a wave share tile images) == dQ of the one-row kernel on the same inputs, including a
     context of more than 65536 keys (second schedule register) and rows with different, unaligned, overlapping ranges"""
     rng = np.random.default_rng(2024)
@@ -437,7 +437,7 @@ def test_backward_query_tile_dq_long_context_and_kernel_switch(nv, monkeypatch):
     rg[0, 5, 1, 2] = (69990, 70000)  # the partial last tile
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("NSA_HIP_SEL_ROWS", mode)
+        tune("SEL_ROWS", mode)
         q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
         nv.selection_attention_hip(q, k, v, dev(rg), variant=2).backward(dO)
         res[mode] = (q.grad, k.grad, v.grad)
@@ -460,3 +460,51 @@ def test_backward_all_ranges_empty_gives_zero_gradients(nv, variant):
     o.backward(torch.randn_like(o))
     for t in (q, k, v):
         assert t.grad is not None and torch.isfinite(t.grad).all() and not t.grad.any()
+
+
+@pytest.mark.parametrize("name", ["ref_test_shape", "a", "b", "c"])
+@pytest.mark.parametrize("dtype,variant", [(torch.float32, 1), (torch.bfloat16, 1), (torch.bfloat16, 2), (torch.float16, 2)])
+def test_g16_backward_matches_reference_autograd(nv, name, dtype, variant):
+    """HIP backward (generic kernel, and the MFMA kernels where the shape is theirs: bf16/f16, Dk = Dv = 64) against dQ/dK/dV from torch
+    autograd through the REFERENCE's grouped_selection_attention_masked (goldens g16, oracle/make_round2_goldens.py; reference
+    test nsa/tests/test_selection_backward_reference.py:35-37).  fp32: 2e-4 absolute / relative; half precision: gradients of the
+    rounded inputs differ from the fp32 golden by the input rounding, bound 6e-2 of the gradient's scale."""
+    g = load_golden("g16_bwd_" + name)
+    Q, K, V, rg, dO = g["Q"], g["K"], g["V"], g["ranges"], g["dO"]
+    if variant == 2 and not (Q.shape[-1] == 64 and V.shape[-1] == 64):
+        pytest.skip("MFMA backward covers Dk = Dv = 64")
+    q, k, v = (dev(x, dtype).requires_grad_(True) for x in (Q, K, V))
+    O = nv.selection_attention_hip(q, k, v, dev(rg), variant=variant)
+    O.backward(dev(dO, dtype))
+    assert np.abs(O.detach().float().cpu().numpy() - g["O"]).max() <= TOL[dtype] * (4 if dtype != torch.float32 else 1)
+    for got, want, what in ((q.grad, g["dQ"], "dQ"), (k.grad, g["dK"], "dK"), (v.grad, g["dV"], "dV")):
+        got = got.float().cpu().numpy()
+        if dtype == torch.float32:
+            assert np.allclose(got, want, atol=2e-4, rtol=2e-4), what
+        else:
+            assert np.abs(got - want).max() <= 6e-2 * max(1.0, np.abs(want).max()), what
+    if name != "ref_test_shape":
+        assert not q.grad[0, 0, 0].any()  # row without a token
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_g17_head_causal_parity_mode_matches_reference(nv, orc, name, dtype):
+    """parity mode of NSAAttention._sdpa_over_ranges (nsa_attention.py:1779-1855; goldens g17 from the imported reference): head i attends
+    the first i+1 gathered tokens.  Also on a strided cache view and with int64 ranges (never modified)."""
+    g = load_golden("g17_head_causal_" + name)
+    Q, K, V, rg = dev(g["Q"], dtype)[:, None], dev(g["K"], dtype), dev(g["V"], dtype), dev(g["ranges"])[:, None]
+    O = nv.selection_attention_head_causal_parity(Q, K, V, rg)[:, 0]
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    assert np.abs(O.float().cpu().numpy() - g["O"]).max() <= tol
+    if dtype != torch.float32:  # half precision: against the oracle on the rounded inputs
+        ref = orc.sel_attention_head_causal_parity(rounded(g["Q"], dtype)[:, None], rounded(g["K"], dtype), rounded(g["V"], dtype),
+                                                   g["ranges"][:, None])[:, 0]
+        assert np.abs(O.float().cpu().numpy() - ref).max() <= 1e-2
+    cache = torch.zeros(V.shape[0], V.shape[1], V.shape[2] + 13, V.shape[3], device="cuda", dtype=dtype)
+    cache[:, :, : V.shape[2]] = V
+    r64 = rg.to(torch.int64)
+    keep = r64.clone()
+    O2 = nv.selection_attention_head_causal_parity(Q, K, cache[:, :, : V.shape[2]], r64)[:, 0]
+    assert torch.equal(O, O2) and torch.equal(r64, keep)
+    assert not O[0, 0].any()

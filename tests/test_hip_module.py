@@ -103,15 +103,21 @@ def test_module_full_gates_runs_and_is_causal():
     assert same >= 0.8
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
-def test_native_layer_path_matches_eager_ops(dtype, tol, monkeypatch):
+@pytest.mark.parametrize("dtype,tol,rope_scale", [(torch.float32, 2e-4, None), (torch.bfloat16, 6e-2, None), (torch.float16, 1e-2, None),
+                                                  (torch.float32, 2e-4, "2.0")])
+def test_native_layer_path_matches_eager_ops(dtype, tol, rope_scale, monkeypatch):
     """inference runs the native layer kernels (fused QKV GEMM -> RoPE + cache append -> pooling -> branches -> gate/combine;
     decode = one nsa_layer_decode_step call); with autograd enabled the module runs the differentiable eager ops around the
     same attention kernels.  Both must give the same layer: learned gates, all three branches, prefill + 40 decode steps."""
     from nsa_vibe_amd.nsa_attention import NSAAttention
 
+    if rope_scale is not None:
+        # NSA_ROPE_SCALE (rope.py:37-43) scales the positions of Q / K_sel / K_win only: the pooled compressed keys are rotated
+        # WITHOUT it (compress_pool.py:20), on the native path as on the eager one (ADVICE r1)
+        monkeypatch.setenv("NSA_ROPE_SCALE", rope_scale)
     torch.manual_seed(1)
     m = NSAAttention(256, 8, 2, 64, 64, l=32, d=16, l_sel=64, n_sel=4, w=96).cuda().to(dtype).eval()
+    assert m.rope_scale == float(rope_scale or 1.0)
     B, S, n_dec = 2, 333, 40
     x = torch.randn(B, S + n_dec, 256, device="cuda", dtype=dtype)
     outs = {}
@@ -605,3 +611,85 @@ def test_force_branch_and_uniform_gate_flags_reach_the_native_paths(flag, monkey
         assert torch.allclose(outs[mode][2].cpu(), want.expand_as(outs[mode][2].cpu()), atol=1e-6)
     for a, e in zip(outs["native"][:2], outs["eager"][:2]):
         assert (a - e).abs().max().item() <= 5e-4
+
+
+@pytest.mark.parametrize("selector", ["sequential", "batched"])
+def test_force_parity_routing_matches_reference_module(selector, monkeypatch):
+    """NSA_FORCE_PARITY=1 (nsa_attention.py:704-708, :1205-1211): the reference drops to its gather executors -- batched prefill to
+    grouped_selection_attention (first gathered key), sequential prefill and decode to _sdpa_over_ranges (head i sees i+1 keys).  The
+    drop-in reads the flag at construction and routes the selected branch to the two parity-mode executors: outputs of the
+    REFERENCE module under that flag (goldens g18, gate forced onto the selected branch) are reproduced, prefill + 40 decode steps."""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    g = load_golden("g18_parity_module")
+    monkeypatch.setenv("NSA_FORCE_PARITY", "1")
+    dim, H, G, dk, dv, l, d, ls, n, w = (int(x) for x in g["cfg"])
+    m = NSAAttention(dim, H, G, dk, dv, l=l, d=d, l_sel=ls, n_sel=n, w=w, selector=selector)
+    m.load_state_dict({k[6:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("state_")})
+    with torch.no_grad():
+        m.gate.fc2.bias.copy_(torch.tensor([-1000.0, 1000.0, -1000.0]))
+    m = m.cuda().eval()
+    assert m._force_parity
+    x_pre, x_dec = torch.from_numpy(g["x_pre"]).cuda(), torch.from_numpy(g["x_dec"]).cuda()
+    with torch.no_grad():
+        out, _ = m(x_pre, m.new_kv(x_pre.shape[0], x_pre.shape[1], "cuda", torch.float32), prefill=True)
+        assert np.abs(out.cpu().numpy() - g[f"out_pre_{selector}"]).max() <= 1e-3
+        if selector == "sequential":
+            kv = m.new_kv(x_dec.shape[1], x_dec.shape[0], "cuda", torch.float32)
+            for i in range(x_dec.shape[0]):
+                o, kv = m(x_dec[i], kv, prefill=False)
+                assert np.abs(o.cpu().numpy() - g["out_dec"][i]).max() <= 1e-3, i
+    # and the flag really changes the route: the semantic executor gives something else on the same weights
+    monkeypatch.setenv("NSA_FORCE_PARITY", "0")
+    m2 = NSAAttention(dim, H, G, dk, dv, l=l, d=d, l_sel=ls, n_sel=n, w=w, selector=selector)
+    m2.load_state_dict(m.state_dict())
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        out2, _ = m2(x_pre, m2.new_kv(x_pre.shape[0], x_pre.shape[1], "cuda", torch.float32), prefill=True)
+    assert (out2 - out).abs().max().item() > 1e-2
+    assert m.get_fallback_counters()["total_fallbacks"] == 0
+
+
+def test_native_call_failure_is_counted_and_raised(monkeypatch):
+    """GPU counterpart of test_cuda_loader_fallback.py: the one-call native prefill fails (status != 0) -> RuntimeError carrying the
+    library's message, selection_hip_fails / total_fallbacks bumped, no other route taken"""
+    from nsa_vibe_amd import _lib
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    torch.manual_seed(0)
+    m = NSAAttention(256, 8, 2, 32, 32, l=32, d=16, l_sel=64, n_sel=8, w=128).cuda().bfloat16().eval()
+    x = torch.randn(1, 200, 256, device="cuda", dtype=torch.bfloat16)
+    real = _lib.lib()
+
+    class Bad:
+        def __getattr__(self, name):
+            if name == "nsa_layer_prefill":
+                return lambda *a: -2
+            return getattr(real, name)
+
+    monkeypatch.setattr(_lib, "_lib", Bad())
+    with torch.no_grad(), pytest.raises(RuntimeError, match="nsa_layer_prefill failed"):
+        m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
+    c = m.get_fallback_counters()
+    assert c["selection_hip_fails"] == 1 and c["total_fallbacks"] == 1
+    monkeypatch.setattr(_lib, "_lib", real)
+    with torch.no_grad():
+        out, _ = m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
+    assert torch.isfinite(out).all() and m.get_fallback_counters()["total_fallbacks"] == 1
+
+
+def test_native_paths_refuse_a_mismatched_cache():
+    """x and the cache must agree in batch / dtype / device before any native call (the kernels walk kv.B sequences)"""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    m = NSAAttention(256, 8, 2, 32, 32, l=32, d=16, l_sel=64, n_sel=8, w=128).cuda().bfloat16().eval()
+    x = torch.randn(2, 100, 256, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="does not match the input"):
+            m(x, m.new_kv(4, 128, "cuda", torch.bfloat16), prefill=True)
+        with pytest.raises(RuntimeError, match="does not match the input"):
+            m(x, m.new_kv(2, 128, "cuda", torch.float16), prefill=True)
+        kv = m.new_kv(2, 128, "cuda", torch.bfloat16)
+        _, kv = m(x, kv, prefill=True)
+        with pytest.raises(RuntimeError, match="does not match the input"):
+            m(x[:1, :1], kv, prefill=False)

@@ -302,9 +302,9 @@ def test_full_size_64k_selection_properties(nv):
 
 
 @pytest.mark.parametrize("S_ctx,B", [(40, 1), (700, 3), (5000, 2), (16400, 1), (65536, 1)])
-def test_fused_decode_scorer_equals_three_kernel_route(nv, S_ctx, B, monkeypatch):
+def test_fused_decode_scorer_equals_three_kernel_route(nv, S_ctx, B, tune):
     """decode: logits -> statistics -> Eq.9/10 -> top-n in one launch must give the ranges (bit-exact) and the output of the
-    three-kernel route (NSA_HIP_DECODE_UNFUSED=1), which the other tests pin against the oracle / reference goldens"""
+    three-kernel route (tuning switch DECODE_UNFUSED = 1), which the other tests pin against the oracle / reference goldens"""
     import torch
 
     g = torch.Generator(device="cuda")
@@ -314,9 +314,9 @@ def test_fused_decode_scorer_equals_three_kernel_route(nv, S_ctx, B, monkeypatch
     Q, Kc = mk(B, 1, 2, 6, 64), mk(B, 2, max(meta.S_cmp, 1), 64)[:, :, : meta.S_cmp]
     K, V = mk(B, 2, S_ctx, 64), mk(B, 2, S_ctx, 64)
     t = S_ctx - 1
-    monkeypatch.delenv("NSA_HIP_DECODE_UNFUSED", raising=False)
+    tune("DECODE_UNFUSED", 0)
     O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, 16, t)
-    monkeypatch.setenv("NSA_HIP_DECODE_UNFUSED", "1")
+    tune("DECODE_UNFUSED", 1)
     O2, r2 = nv.selection_decode_step(Q, Kc, K, V, meta, 16, t)
     torch.cuda.synchronize()
     assert torch.equal(r1, r2)

@@ -209,3 +209,25 @@ def test_g15_first_key_parity_mode(orc, name):
     """oracle restatement of the reference's packed / gather executors (attention_kernels.py:181-226, 273-388): V at the first key"""
     g = load_golden("g15_first_key_" + name)
     assert np.array_equal(orc.sel_attention_first_key_parity(g["Q"], g["V"], g["ranges"]), g["O"])
+
+
+@pytest.mark.parametrize("name", ["ref_test_shape", "a", "b", "c"])
+def test_g16_backward_oracle_matches_reference_autograd(orc, name):
+    """oracle backward == torch autograd through the reference's grouped_selection_attention_masked (attention_kernels.py:705-772),
+    taken as nsa/tests/test_selection_backward_reference.py:35-37 takes it; tolerance = that test's 1e-5"""
+    g = load_golden("g16_bwd_" + name)
+    dQ, dK, dV = orc.sel_attention_masked_bwd(g["Q"], g["K"], g["V"], g["ranges"], g["dO"])
+    for got, want in ((dQ, g["dQ"]), (dK, g["dK"]), (dV, g["dV"])):
+        assert np.allclose(got, want, atol=1e-5, rtol=1e-5)
+    assert np.abs(orc.sel_attention_masked(g["Q"], g["K"], g["V"], g["ranges"]) - g["O"]).max() <= 1e-5
+    if name != "ref_test_shape":
+        assert not g["dQ"][0, 0, 0].any()  # the row without a token has no gradient in the reference either
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_g17_head_causal_parity_mode(orc, name):
+    """oracle restatement of NSAAttention._sdpa_over_ranges (nsa_attention.py:1779-1855): head i sees the first i+1 gathered tokens"""
+    g = load_golden("g17_head_causal_" + name)
+    O = orc.sel_attention_head_causal_parity(g["Q"][:, None], g["K"], g["V"], g["ranges"][:, None])[:, 0]
+    assert np.abs(O - g["O"]).max() <= 1e-5
+    assert not O[0, 0].any()

@@ -18,7 +18,7 @@ for S, B in shapes:
     p = nv.selection_scores(Q, Kc, meta, 0.125, causal_skip=True)
     res = {}
     for mode in ("0", "1", "3"):
-        os.environ["NSA_HIP_SEL_ROWS"] = mode
+        nv._lib.set_tuning("SEL_ROWS", int(mode))
         f = lambda: nv.select_and_attend(p, Q, K, V, meta, 16, mode="batched", scale=0.125)  # noqa: E731
         for _ in range(3):
             f()

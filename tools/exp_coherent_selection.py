@@ -21,7 +21,7 @@ for c in (0.0, 0.5, 0.9, 1.0):
     p = (c * shared + (1 - c) * rnd).contiguous()
     line = f"coherence {c:.1f}:"
     for mode, name in (("0", "one-row"), ("1", "pairs"), ("3", "48-slot")):
-        os.environ["NSA_HIP_SEL_ROWS"] = mode
+        nv._lib.set_tuning("SEL_ROWS", int(mode))
         f = lambda: nv.select_and_attend(p, Q, K, V, meta, 16, mode="batched", scale=0.125)  # noqa: E731
         for _ in range(3):
             f()

@@ -17,7 +17,7 @@ rg1 = rg0.clone()
 rg1[..., 0, 1] = 32  # one tile per row
 for name, rg in (("empty", rg0), ("one tile", rg1)):
     for mode in ("0", "1"):
-        os.environ["NSA_HIP_SEL_ROWS"] = mode
+        nv._lib.set_tuning("SEL_ROWS", int(mode))
         f = lambda: nv.selection_attention_hip(Q, K, V, rg)  # noqa: E731
         for _ in range(3):
             f()
