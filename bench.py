@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the selected-branch attention hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N>1 without WORLD_SIZE: bench.py starts the N ranks itself)
 
 A "step" = one pass of the hot path over one batch of synthetic input for one layer:
     Q,K_cmp -> p_grp (softmax scores, Eq.9, Eq.10) -> deterministic top-n ranges -> selection attention
 (two launches: the fused scorer, then one kernel that selects the row's ranges and attends over them)
-on the m7c_125m shape (dim 768: 12 heads, G=2, h=6, d_k=d_v=64; l=32 d=16 l'=64 n=16), S=4096, bf16,
-B sequences per GPU (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.
-Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequences, no data-path
-collective exists on this path (weak scaling); time = max over ranks.
+on the m7c_125m shape (dim 768: 12 heads, G=2, h=6, d_k=d_v=64; l=32 d=16 l'=64 n=16) at S=65536 (north_star's target
+length, BASELINE.json configs[3]), bf16, B=16 sequences per GPU: K/V = 512 MiB, twice the Infinity Cache, so the inputs
+really live in HBM.  Inputs are resident in HBM before the timed region.  (--seq/--batch select the other BASELINE shapes;
+S=4096 B=8, S=16384 and S=65536 B=1 are reported under `extra`.)
+Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequences, no data-path collective exists on this
+path (weak scaling); time = max over ranks.
 
 The JSON line also carries
-  roofline     dominant kernel (selection attention): algorithmic gather bytes / HIP-event kernel time
-               vs the 8 TB/s HBM peak (L_row*(Dk+Dv)*sizeof per (b,t,g) row)
-  cpu_baseline the CPU oracle (a port of the reference path, validated against the reference) timed on
-               this node's host cores on a bounded sample of the same workload
-  extra        decode tok/s and prefill ms at S in {4k,16k,64k} of the hot path, MFMA TFLOP/s of the attention kernel,
-               selection backward, the sliding/compressed branch kernel, and the whole NSAAttention layer (native path)
+  roofline         dominant kernel of the step (select + attend, one launch).  In prefill every K/V row is gathered ~L/S*n
+                   times, so the gather is served by L2 / Infinity Cache and is NOT an HBM stream: the roof that bounds the
+                   in-block QK^T / PV work is the dense bf16 MFMA peak (bound "mfma": algorithmic flops 4*h*L*D per row over
+                   HIP-event kernel time vs 2.5 PFLOP/s); the gathered bytes vs the aggregate L2 bandwidth and the PMC HBM
+                   traffic per launch (profiles/r02/traffic_*.json) are reported beside it.
+  decode_roofline  the HBM-bound configuration north_star names: one decode step of B sequences at context S reads
+                   sum_rows L_row*(Dk+Dv)*2 B of selected K/V plus the compressed keys (S_cmp*Dk*2 B per (b,g)) exactly once
+                   (reads formula of nsa/core/nsa_attention.py:634-635, bytes formula of triton_sel_kernel/__init__.py:483);
+                   achieved = those bytes / step time vs the 8 TB/s HBM peak.
+  cpu_baseline     the CPU oracle (a port of the reference path, validated against the reference) timed on this node's host
+                   cores on a bounded sample of the same workload
+  extra            decode tok/s and prefill ms at S in {4k,16k,64k} of the hot path, MFMA TFLOP/s of the attention kernel,
+                   selection backward, the sliding/compressed branch kernel, and the whole NSAAttention layer (native path)
 """
 import argparse
 import json
@@ -88,24 +97,32 @@ def gathered_tiles(ranges, S_kv, tpw):
     """32-key K/V tiles the query-tile kernel really brings into LDS: the union over the tpw rows one wave owns (sel_attn_rows_mfma.hip)"""
     Bq, Sq, Gq = ranges.shape[:3]
     nt = (S_kv + 31) // 32
-    s, e = ranges[..., 0].long().clamp(0, S_kv), ranges[..., 1].long().clamp(0, S_kv)
-    live = (e > s).to(torch.int32)
-    diff = torch.zeros(Bq, Sq, Gq, nt + 1, dtype=torch.int32, device=ranges.device)
-    diff.scatter_add_(3, (s >> 5).clamp(max=nt), live)
-    diff.scatter_add_(3, (((e - 1).clamp_min(0) >> 5) + 1).clamp(max=nt), -live)
-    cover = diff.cumsum(3)[..., :nt] > 0
-    Sp = Sq // tpw * tpw
-    n = cover[:, :Sp].reshape(Bq, Sp // tpw, tpw, Gq, nt).any(2).sum()
-    if Sp < Sq:
-        n = n + cover[:, Sp:].any(1).sum()
-    return float(n.item())
+    total = 0.0
+    for b in range(Bq):  # one sequence at a time: the cover map of a 64k sequence is 0.5 GB
+        rb = ranges[b: b + 1]
+        s, e = rb[..., 0].long().clamp(0, S_kv), rb[..., 1].long().clamp(0, S_kv)
+        live = (e > s).to(torch.int16)
+        diff = torch.zeros(1, Sq, Gq, nt + 1, dtype=torch.int16, device=ranges.device)
+        diff.scatter_add_(3, (s >> 5).clamp(max=nt), live)
+        diff.scatter_add_(3, (((e - 1).clamp_min(0) >> 5) + 1).clamp(max=nt), -live)
+        cover = diff.cumsum(3, dtype=torch.int16)[..., :nt] > 0
+        del diff
+        Sp = Sq // tpw * tpw
+        n = cover[:, :Sp].reshape(1, Sp // tpw, tpw, Gq, nt).any(2).sum()
+        if Sp < Sq:
+            n = n + cover[:, Sp:].any(1).sum()
+        total += float(n.item())
+        del cover
+    return total
 
 
 def decode_bench(nv, B, S_ctx, steps, device):
     """Decode-shaped hot path: B sequences at context S_ctx, one new token each (sequential-mode selector,
-    preallocated K/V cache passed as a strided view -- no torch.cat append as in nsa/cache/kv_cache.py:28-30)."""
+    preallocated K/V cache passed as a strided view -- no torch.cat append as in nsa/cache/kv_cache.py:28-30).
+    Returns tok/s, ms per step and the bytes one step must read (every one of them exactly once: the HBM roofline of decode)."""
     meta, Q, Kc, K, V = make_inputs(nv, B, S_ctx, device, 7)
     q1 = Q[:, -1:].contiguous()
+    del Q
     t = S_ctx - 1
 
     O = torch.empty(B, 1, G, H, D, device=device, dtype=torch.bfloat16)
@@ -115,7 +132,23 @@ def decode_bench(nv, B, S_ctx, steps, device):
         return nv.selection_decode_step(q1, Kc, K, V, meta, N_SEL, t, out=O, ranges_out=rg)
 
     ms = time_events(step, steps, warm=3)
-    return B / (ms * 1e-3), ms
+    L = float((rg[..., 1] - rg[..., 0]).clamp_min(0).sum().item())  # selected tokens over all (b,g) rows
+    gather_bytes = L * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V once per group (triton_sel_kernel/__init__.py:483)
+    kcmp_bytes = float(B * G * meta.S_cmp * D * 2)  # the scorer reads every compressed key of every (b,g) once
+    return {"tok_per_s": B / (ms * 1e-3), "ms_per_step": ms, "context": S_ctx, "batch": B, "selected_tokens_per_row": L / (B * G),
+            "gather_bytes": gather_bytes, "kcmp_bytes": kcmp_bytes, "kv_resident_bytes": float(2 * B * G * S_ctx * D * 2)}
+
+
+def decode_roofline(d, traffic):
+    """HBM roofline of one decode step: bytes that must be read once / step time vs the 8 TB/s peak"""
+    alg = d["gather_bytes"] + d["kcmp_bytes"]
+    ach = alg / (d["ms_per_step"] * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+            "algorithmic_bytes_per_step": alg, "gather_bytes": d["gather_bytes"], "kcmp_bytes": d["kcmp_bytes"],
+            "step_ms": d["ms_per_step"], "workload": f"decode step, B={d['batch']} sequences at context {d['context']} "
+            f"(K/V resident: {d['kv_resident_bytes'] / 2 ** 20:.0f} MiB), one native call (scores -> top-n -> attention)",
+            "formula": "sum_rows L_row*(Dk+Dv)*2 B + B*G*S_cmp*Dk*2 B, each read once (nsa_attention.py:634-635; "
+                       "triton_sel_kernel/__init__.py:483)"}
 
 
 def band_bench(nv, B, S, device, iters=5):
@@ -246,45 +279,57 @@ def model_bench(B, S, device, steps=24):
 
 
 def cpu_baseline(S, B, seed=3, min_seconds=10.0):
-    """The oracle (CPU restatement of the reference path, fp32) on the same workload, repeated over the batch
-    until ~10 s of host time have been spent (bounded sample)."""
+    """The oracle (CPU restatement of the reference path, fp32) on the same workload.  Bounded sample: at S <= 8192 whole
+    sequences, repeated until ~10 s of host time have been spent; beyond that every `stride`-th query row of one sequence
+    (scores and attention on the sampled rows against the FULL K_cmp / K / V; the batched selector runs over all rows and is
+    charged pro rata), repeated until ~10 s."""
     from oracle import nsa_oracle as orc
 
     orc.build()
     rng = np.random.default_rng(seed)
     meta = orc.build_block_meta(S, L_CMP, D_CMP, L_SEL, N_SEL, 512)
     S_cmp = meta.cmp_starts.size
-    Q = rng.standard_normal((1, S, G, H, D), dtype=np.float32)
+    stride = 1 if S <= 8192 else S // 4096
+    rows = np.arange(stride // 2, S, stride)
+    Q = rng.standard_normal((1, rows.size, G, H, D), dtype=np.float32)
     Kc = rng.standard_normal((1, G, S_cmp, D), dtype=np.float32)
     K = rng.standard_normal((1, G, S, D), dtype=np.float32)
     V = rng.standard_normal((1, G, S, D), dtype=np.float32)
     tot = [0.0, 0.0, 0.0]
-    nseq = 0
-    while sum(tot) < min_seconds and nseq < 64 * B:
+    nrep = 0
+    p_full = np.zeros((1, S, G, meta.sel_starts.size), np.float32) if stride > 1 else None
+    while sum(tot) < min_seconds and nrep < 64 * B:
         t0 = time.perf_counter()
         p_cmp = orc.compute_pcmp_all(Q, Kc, 1.0 / 8.0)
         _, p_grp = orc.map_pcmp_to_pslc_and_pgrp(p_cmp, meta)
+        del p_cmp
         t1 = time.perf_counter()
-        r = orc.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
+        if stride > 1:
+            p_full[0, rows] = p_grp[0]
+            r = orc.select_topn_ranges_batched(p_full, meta, N_SEL, S)[:, rows]
+        else:
+            r = orc.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
         t2 = time.perf_counter()
         orc.sel_attention_masked(Q, K, V, r)
         t3 = time.perf_counter()
-        tot = [tot[0] + t1 - t0, tot[1] + t2 - t1, tot[2] + t3 - t2]
-        nseq += 1
-    return {"value": nseq * S / sum(tot), "unit": "tok/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{nseq} sequences of S={S} (m7c, fp32, every row), OpenMP over rows: scores {tot[0]:.2f}s "
-                      f"select {tot[1]:.2f}s attention {tot[2]:.2f}s",
+        tot = [tot[0] + t1 - t0, tot[1] + (t2 - t1) / stride, tot[2] + t3 - t2]
+        nrep += 1
+    what = (f"{nrep} sequences of S={S} (every row)" if stride == 1 else
+            f"{nrep} x {rows.size} query rows (every {stride}th row) of one S={S} sequence against the full K_cmp/K/V, selector pro rata")
+    return {"value": nrep * rows.size / sum(tot), "unit": "tok/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{what} (m7c, fp32), OpenMP over rows: scores {tot[0]:.2f}s select {tot[1]:.2f}s attention {tot[2]:.2f}s",
             "cpu_model": _cpu_model()}
 
 
-def pmc_traffic(S, B):
-    """HBM bytes per launch of the attention kernel for this workload, measured with rocprofv3 PMC counters in separate
-    passes and committed under profiles/ (bench.py cannot run the profiler on itself); None if not measured."""
-    path = os.path.join(ROOT, "profiles", "r01", f"traffic_S{S}_B{B}.json")
-    try:
-        return float(json.load(open(path))["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
+def pmc_traffic(tag, key="traffic_bytes"):
+    """HBM bytes per launch for a workload, measured with rocprofv3 PMC counters in separate passes (tools/pmc_traffic.sh) and
+    committed under profiles/ (bench.py cannot run the profiler on itself); None if not measured."""
+    for rnd in ("r02", "r01"):
+        try:
+            return float(json.load(open(os.path.join(ROOT, "profiles", rnd, f"traffic_{tag}.json")))[key])
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def _cpu_model():
@@ -421,14 +466,74 @@ def train_model_mode(nv, args, dist, world, rank, device):
         dist.destroy_process_group()
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher environment: start the N ranks ourselves, BEFORE anything touches the GPU --
+    a child `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1); this process only waits and exits
+    with the child's code (never re-exec: a process that has initialised the GPU must not be replaced).  PG-init pattern of the
+    reference's trainer: scripts/train_showcase.py:425-437."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def dry_main(args, world, rank):
+    """--dry: the multi-rank plumbing of the bench (rendezvous, barrier, max-over-ranks timing, one JSON line from rank 0) on the CPU
+    with the gloo backend and a stand-in step -- what the world-size-2 CPU test runs.  Never a measurement."""
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend)
+    x = torch.ones(64, 64) * (rank + 1)
+
+    def step():
+        return (x @ x).sum()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        seen = torch.tensor([1.0])
+        dist.all_reduce(seen)
+        assert int(seen.item()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "dry_run_plumbing_only", "value": world * args.batch * args.seq / max(elapsed / args.steps, 1e-9), "unit": "tok/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "dry run (CPU, no kernels): launcher / rendezvous / timing plumbing only",
+                                     "global_batch": world * args.batch, "parallelism": f"{world} rank(s), backend {args.backend}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
-    ap.add_argument("--seq", type=int, default=4096)
-    ap.add_argument("--no-extra", action="store_true", help="skip the decode / 16k / 64k extras and the CPU baseline")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default 16 at S=65536, 8 otherwise)")
+    ap.add_argument("--seq", type=int, default=65536)
+    ap.add_argument("--no-extra", action="store_true", help="skip the decode / 4k / 16k extras and the CPU baseline")
     ap.add_argument("--train", action="store_true",
                     help="instead of the hot path: forward+backward of the whole NSAAttention layer under DistributedDataParallel "
                          "(BASELINE config 5: gradient all-reduce over RCCL/xGMI, batch sharded over the ranks)")
@@ -437,11 +542,27 @@ def main():
                          "(BASELINE config 5 in full: 12 NSA blocks, cross-entropy, clip, fused AdamW)")
     ap.add_argument("--layers", type=int, default=12, help="--train-model: number of blocks")
     ap.add_argument("--vocab", type=int, default=50257, help="--train-model: vocabulary (GPT-2, as configs/m7c_125m_80g.yaml)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --dry)")
+    ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the multi-rank plumbing (no GPU, no kernels, no measurement)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 16 if (args.seq >= 65536 and not (args.train or args.train_model)) else 8
+        if args.train or args.train_model:
+            args.seq = 4096 if args.seq == 65536 else args.seq  # config 5 is quoted at S=4096
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))  # nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to report a mislabelled run", file=sys.stderr)
+        sys.exit(2)
+    if args.dry:
+        return dry_main(args, world, rank)
+    if args.backend != "nccl":
+        print("bench.py: measurements run over RCCL (--backend nccl); gloo is for --dry only", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -483,47 +604,72 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     value = world * B * S / (elapsed / args.steps)
 
+    kv_mib = 2 * B * G * S * D * 2 / 2 ** 20
     out = {
         "metric": "sel_branch_hot_path_prefill_tok_per_s", "value": value, "unit": "tok/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"m7c_125m selected-branch hot path (scores->top-n ranges->selection attention), one layer, "
-                               f"S={S}, B={B} per GPU, G={G} h={H} d_k=d_v={D}, l={L_CMP} d={D_CMP} l'={L_SEL} n={N_SEL}",
+                               f"S={S}, B={B} per GPU (K/V {kv_mib:.0f} MiB resident in HBM), G={G} h={H} d_k=d_v={D}, l={L_CMP} d={D_CMP} "
+                               f"l'={L_SEL} n={N_SEL}",
                    "global_batch": world * B, "seq_len": S, "parallelism": f"batch x group shard over {world} GPU(s), no collective"},
     }
     if rank == 0:
         t_sc, t_sel, t_att, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
         gathered = n_tiles * 32 * (D + D) * 2
         alg_bytes = Lsum * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V counted once per group
-        achieved = alg_bytes / (t_att * 1e-3) / 1e9
-        flops = 4.0 * H * Lsum * D
-        out["roofline"] = {"kernel": "sel_attn_rows_mfma_kernel<bf16,64,1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(S, B),
-                           "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01/traffic_*.json); the gather is "
-                                           "L2 / Infinity-Cache resident, so achieved (algorithmic) exceeds what reaches HBM",
-                           "l2_peak": L2_PEAK_GBPS, "gathered_bytes_per_launch": gathered,
-                           "l2_frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS,
-                           "l2_note": "the XCD-aware (b,g)-major order keeps one pair's K/V (1 MiB at S=4096) in its XCD's 4 MiB L2: the gather "
-                                      "runs against the aggregate L2 bandwidth, not HBM.  gathered = the 32-key tiles really brought into LDS "
-                                      "(two rows of one wave share a tile both selected), algorithmic = the per-row figure of SURVEY 8(d)",
-                           "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
-                           "mfma_tflops": flops / (t_att * 1e-3) / 1e12, "mfma_frac": flops / (t_att * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-        out["stages_ms"] = {"scores": t_sc, "select_and_attention_one_launch": t_att, "select_standalone_kernel": t_sel}
+        flops = 4.0 * H * Lsum * D  # 2*h*L*Dk (QK^T) + 2*h*L*Dv (PV) per row
+        tfl = flops / (t_att * 1e-3) / 1e12
+        traffic = pmc_traffic(f"S{S}_B{B}")
+        out["roofline"] = {
+            "kernel": "select + attend (one launch: top-n selection of the row, then its block-sparse attention)", "bound": "mfma",
+            "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+            "qk_frac": 0.5 * tfl / MFMA_BF16_PEAK_TFLOPS,
+            "why_not_hbm": "prefill gathers every K/V row many times (algorithmic gather below vs the unique K/V above): the gather is served "
+                           "by L2 / Infinity Cache, PMC HBM traffic per launch is `traffic`; the HBM-bound configuration is decode_roofline",
+            "algorithmic_flops_per_launch": flops, "algorithmic_gather_bytes_per_launch": alg_bytes,
+            "gathered_bytes_per_launch": gathered, "gather_GBps": gathered / (t_att * 1e-3) / 1e9, "l2_peak": L2_PEAK_GBPS,
+            "l2_frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS,
+            "l2_note": "gathered = the K/V tiles really brought into LDS (rows of one wave share a tile they both selected) vs the ~34.5 TB/s "
+                       "aggregate L2 bandwidth of the guide; algorithmic = the per-row figure of SURVEY 8(d)",
+            "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
+            "hbm_traffic_frac_of_peak": (traffic / (t_att * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None}
+        out["stages_ms"] = {"scores": t_sc, "select_and_attention_one_launch": t_att, "select_standalone_kernel": t_sel,
+                            "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
+                                    "so scores + select_and_attention can exceed it slightly.  select_standalone_kernel is not part of the step"}
+        flops_sc = 2.0 * B * S * G * H * meta.S_cmp * D
+        out["roofline_scores"] = {"kernel": "scores_mfma_kernel (fused p_cmp softmax + Eq.9 + Eq.10)", "bound": "mfma",
+                                  "achieved": flops_sc / (t_sc * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": flops_sc / (t_sc * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "kernel_ms": t_sc,
+                                  "note": "algorithmic flops 2*B*S*heads*S_cmp*Dk (one pass; the kernel sweeps K_cmp twice because the "
+                                          "reference normalises over all compressed columns)"}
+        del Q, Kc, K, V
+        torch.cuda.empty_cache()
         if not args.no_extra and world == 1:
             extra = {}
             try:
-                for Bd in (1, 64):
-                    tok_s, ms = decode_bench(nv, Bd, 65536 if Bd == 1 else 16384, 30, device)
-                    extra[f"decode_B{Bd}"] = {"tok_per_s": tok_s, "ms_per_step": ms, "context": 65536 if Bd == 1 else 16384}
-                for S2, B2 in ((4096, 1), (16384, 1), (65536, 1)):
+                for Bd, Sd in ((64, 16384), (64, 65536), (1, 65536)):
+                    d = decode_bench(nv, Bd, Sd, 30, device)
+                    extra[f"decode_B{Bd}_S{Sd}"] = d
+                    rl = decode_roofline(d, pmc_traffic(f"decode_B{Bd}_S{Sd}"))
+                    if Bd == 64 and Sd == 16384:
+                        out["decode_roofline"] = rl
+                    else:
+                        extra[f"decode_roofline_B{Bd}_S{Sd}"] = rl
+                for S2, B2 in ((4096, 8), (4096, 1), (16384, 1), (65536, 1)):
                     m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
-                    ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 3, warm=1)
-                    sc, se, at, Ls, Lm, _ = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 3)
-                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "scores_ms": sc, "select_standalone_ms": se, "select_and_attention_ms": at,
-                                                    "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9, "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12}
+                    ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 5, warm=2)
+                    sc, se, at, Ls, Lm, nt2 = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 5)
+                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "tok_per_s": B2 * S2 / (ms * 1e-3), "scores_ms": sc, "select_standalone_ms": se,
+                                                    "select_and_attention_ms": at, "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9,
+                                                    "attn_gathered_GBps": nt2 * 32 * 256 / (at * 1e-3) / 1e9,
+                                                    "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12,
+                                                    "attn_mfma_frac": 4.0 * H * Ls * D / (at * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                                    "hbm_traffic": pmc_traffic(f"S{S2}_B{B2}")}
+                    if S2 == 4096 and B2 == 8:
+                        extra[f"sel_attn_fwd_bwd_S{S2}_B{B2}"] = backward_bench(nv, m2, Q2, K2, V2, S2)
                     del m2, Q2, Kc2, K2, V2
-                # next scope rows: backward, the sliding/compressed branch kernel (MFMA bound), the whole layer on the native path
-                extra[f"sel_attn_fwd_bwd_S{S}_B{B}"] = backward_bench(nv, meta, Q, K, V, S)
+                # next scope rows: the sliding/compressed branch kernel (MFMA bound), the whole layer on the native path
                 for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
                     extra[f"band_S{S2}_B{B2}"] = band_bench(nv, B2, S2, device)
                 bw = extra["band_S65536_B1"]["cmp"]
@@ -532,7 +678,7 @@ def main():
                                         "frac": bw["tflops"] / MFMA_BF16_PEAK_TFLOPS, "kernel_ms": bw["ms"]}
                 for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
                     extra[f"layer_S{S2}_B{B2}"] = layer_bench(nv, B2, S2, device)
-                extra[f"layer_train_S{S}_B{B}"] = layer_train_bench(nv, B, S, device)
+                extra["layer_train_S4096_B8"] = layer_train_bench(nv, 8, 4096, device)
                 # the whole m7c_125m model (BASELINE configs 2-4 name it): attention layers native, norms / MLP / head PyTorch-ROCm
                 for S2, B2 in ((4096, 1), (16384, 1), (4096, 32)):
                     extra[f"model_m7c_125m_S{S2}_B{B2}"] = model_bench(B2, S2, device)

@@ -366,3 +366,26 @@ def test_tuning_switches_roundtrip():
         _lib.set_tuning("SEL_ROWS", old)
     with pytest.raises(RuntimeError, match="unknown tuning switch"):
         _lib.set_tuning("NO_SUCH_SWITCH", 1)
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks: rehearsed on the CPU with
+    --dry --backend gloo (rendezvous on 127.0.0.1, barrier, max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = 2); a
+    launcher that started a different number of ranks than --gpus says is refused"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2 * 16
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode == 2 and "refusing" in r.stderr

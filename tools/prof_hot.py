@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Focused workloads for rocprofv3 passes (kernel trace or PMC): the hot path of bench.py at one shape, a few launches.
+
+    ... -- python3 tools/prof_hot.py prefill <S> <B> <iters> [attn|scores|all]     (select + attend launch / scorer / both)
+    ... -- python3 tools/prof_hot.py decode  <B> <S_ctx> <iters>                   (nsa_sel_decode_step)
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import nsa_vibe_amd as nv  # noqa: E402
+
+mode = sys.argv[1]
+dev = torch.device("cuda", 0)
+if mode == "prefill":
+    S, B, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    stage = sys.argv[5] if len(sys.argv) > 5 else "all"
+    meta, Q, Kc, K, V = bench.make_inputs(nv, B, S, dev, 1234)
+    p = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        if stage in ("scores", "all"):
+            p = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
+        if stage in ("attn", "all"):
+            nv.select_and_attend(p, Q, K, V, meta, bench.N_SEL, mode="batched")
+    torch.cuda.synchronize()
+else:
+    B, S, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    meta, Q, Kc, K, V = bench.make_inputs(nv, B, S, dev, 7)
+    q1 = Q[:, -1:].contiguous()
+    del Q
+    O = torch.empty(B, 1, bench.G, bench.H, bench.D, device=dev, dtype=torch.bfloat16)
+    rg = torch.empty(B, bench.G, bench.N_SEL, 2, device=dev, dtype=torch.int32)
+    for _ in range(iters + 2):
+        nv.selection_decode_step(q1, Kc, K, V, meta, bench.N_SEL, S - 1, out=O, ranges_out=rg)
+    torch.cuda.synchronize()
