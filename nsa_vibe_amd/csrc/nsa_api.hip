@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, 0, -1};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "DECODE_STOP"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, 0, -1, -1, 0};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -173,6 +173,9 @@ int nsa::sel_attn_fwd_impl(const void *Q, const void *K, const void *V, const in
                          ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0);
     if (variant == 2) NSA_CHECK_ARG(fast_ok, "sel_attn_fwd: MFMA variant requested but shape/dtype/alignment unsupported");
     NSA_CHECK_ARG(variant >= 0 && variant <= 2, "sel_attn_fwd: unknown variant %d", variant);
+    if (variant == 0 && S == 1 && !lse && sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_ranges, kss, vss, Q, K, V) &&
+        (int64_t)S_kv * 128 < ((int64_t)1 << 31))  // decode: one workgroup per row, partials merged through LDS, no combine launch
+        return launch_sel_attn_decode_wg(Q, K, V, ranges, O, R, G, h, S_kv, n_ranges, ksb, ksg, kss, vsb, vsg, vss, dtype, P.scale, st);
     if (variant == 2 || (variant == 0 && fast_ok)) {
         int ns = 1;
         const size_t need = sel_attn_mfma_workspace(R, h, Dv, &ns);
@@ -606,10 +609,18 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
     const size_t p = align16(sizeof(float) * (size_t)B * G * (size_t)(S_sel > 0 ? S_sel : 1));
     float *p_grp = (float *)(w + a);
     int rc;
+    const float sc = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
+    const bool wg_attn = sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, kss, vss, Q, K, V) && S_kv >= 1 &&
+                         (int64_t)S_kv * 128 < ((int64_t)1 << 31);
     if (decode_score_select_supported(dtype, h, Dk, S_cmp, S_sel, kcb, kcg, kcs, Q, K_cmp)) {
+        if (wg_attn) {  // scores -> statistics -> Eq.9/10 -> sequential top-n -> selection attention: ONE launch, O is final
+            if (ns_used) *ns_used = 1;
+            return launch_decode_score_select_attend(Q, K_cmp, K, V, O, B, G, h, Dk, S_cmp, S_kv, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg, vss, csc_ptr,
+                                                     csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype, sc, ranges_out, (hipStream_t)stream);
+        }
         // scores -> statistics -> Eq.9/10 -> sequential top-n in one launch (bit-identical to the route below)
         rc = launch_decode_score_select(Q, K_cmp, B, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token,
-                                        dtype, scale > 0.f ? scale : 1.0f / sqrtf((float)Dk), ranges_out, (hipStream_t)stream);
+                                        dtype, sc, ranges_out, (hipStream_t)stream, nullptr);
         if (rc) return rc;
     } else {
         rc = nsa_sel_scores(Q, K_cmp, p_grp, B, 1, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l, d, l_sel, 1,

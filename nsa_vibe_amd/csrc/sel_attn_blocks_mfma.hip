@@ -1,0 +1,454 @@
+// Block form of the MFMA selection attention (prefill / training forward; bf16 / f16, Dk = Dv = 64).
+//
+// Why: the query-tile kernel (sel_attn_rows_mfma.hip, NT = 1) is bound by two things its structure fixes (PMC r01/n_*): ~21
+// VALU+SALU instructions per MFMA (per-32-key-tile schedule walk, ballots, masks, DMA set-up) and the CU's vector-memory path
+// (64 B/clk/CU): every row pair pulls each of its tiles through L1 -> LDS on its own, 10 GB per launch at S=4096, B=8.
+// Here a wave owns NT column tiles of 16/h consecutive rows each (h = 6: NT = 4 -> 8 rows) and walks the UNION of their selected
+// 64-key blocks (= the selection block l' of the reference geometry):
+//   * a block is brought into wave-private LDS ONCE by LDS-DMA (16 KiB, 16 wave-instructions) and its K / V^T fragments are read
+//     into registers once; every column tile whose rows selected the block then runs 8 + 8 MFMAs from those registers, tiles
+//     none of whose rows touch the block are skipped by one scalar test.  At S = 4096 the union of 8 rows is ~0.4 x the sum of
+//     their selections: that factor comes off the L1 -> LDS traffic and off the LDS reads;
+//   * per-block overhead (schedule walk, two ballots, DMA issue, waits) is paid per 64 keys x up to NT tiles, not per 32 keys;
+//   * a slot whose row did not select the block gets -inf through the softmax offset (ONE v_cndmask per tile; x = s*c2 - inf);
+//     only blocks a row covers PARTIALLY (the causal clamp at t+1 of the sequential selector, unaligned user ranges, the tail
+//     of K/V) take the masked path with a per-row 64-bit key mask rebuilt from the row's ranges.
+// Semantics are those of every selection executor here: union of the clamped ranges, end <= start ignored, empty row -> zeros
+// (attention_kernels.py:705-772).  Softmax (exp2 domain, deferred max), S^T / O^T formulation, swizzled LDS image and epilogue
+// are those of sel_attn_rows_mfma.hip; outputs agree with it to rounding (same products, the key order inside a block is the same).
+#include "attn_mfma_tiles.hpp"
+#include "sel_select_row.hpp"
+
+namespace nsa {
+
+namespace blk {
+constexpr int D = 64, ROWB = 128, KS = 2, MT = 4;
+constexpr int BLK = 64;                 // keys per block
+constexpr int TILE_BYTES = BLK * ROWB;  // 8 KiB per operand
+__device__ __forceinline__ unsigned span(int lo, int hi) {  // bits lo..hi inclusive, 0 <= lo <= hi <= 31
+    const unsigned up = hi >= 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u);
+    return up & ~((1u << lo) - 1u);
+}
+__device__ __forceinline__ void lds_or(unsigned *p, unsigned v) {
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    __hip_atomic_fetch_or((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+// one v_max3_f32 (fmaxf makes hipcc canonicalise each MFMA-derived operand with a v_max x,x first: 16 extra VALU per tile)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+}  // namespace blk
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
+    using namespace blk;
+    using M = MfmaT<T>;
+    using x8 = typename M::x8;
+    using x4 = typename M::x4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int h = P.h, NW = P.nw, n = P.n;
+    const int tpt = P.tpw;       // rows per column tile (16 / h)
+    const int tpw = NT * tpt;    // rows per wave
+    const int ngrp = (P.S + tpw - 1) / tpw;  // row groups per (b,g)
+    const int nbg = (int)(P.R / P.S);
+    const int W4 = (ngrp + 3) >> 2;  // workgroups per (b,g)
+    int bg, tc;
+    if (P.map_mode == 2) {  // whole (b,g) pairs per XCD (workgroups go round-robin over the 8 XCDs)
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bg = (idx / W4) * 8 + xcd;
+        tc = idx % W4;
+    } else {
+        bg = blockIdx.x / W4;
+        tc = blockIdx.x % W4;
+    }
+    const int grp = 4 * tc + wave;
+    if (grp >= ngrp || bg >= nbg) return;
+    const int b = bg / P.G, g = bg - b * P.G;
+    const int tw0 = grp * tpw, ntok = min(tpw, P.S - tw0);
+
+    unsigned char *kl = smem + (size_t)wave * P.wave_lds;
+    unsigned char *vl = kl + TILE_BYTES;
+    int *rg = (int *)(vl + TILE_BYTES);                              // [tpw][n][2] clamped ranges
+    unsigned *fullw = (unsigned *)(rg + ((2 * tpw * n + 3) & ~3));   // [tpw][NW] blocks a single range of the row covers completely
+    unsigned *touchw = fullw + tpw * NW;                             // [tpw][NW] blocks with at least one selected key
+    unsigned *kmask = touchw + tpw * NW;                             // [tpw][2]  64-bit key mask of a partially covered block
+
+    // ---- per-slot constants; the Q loads go out first so that their latency runs under the range / bitmap work below
+    const int rho = lane & 15, q = lane >> 4;
+    const int tsub = rho / h, head = rho - tsub * h;  // row inside the column tile, head
+    int tokn[NT];
+    unsigned rowbit[NT];  // bit of the slot's row in the ownership masks, 0 for an unused slot
+    unsigned nmask[NT];   // rows of column tile nn (wave uniform)
+    x8 qf[NT][KS];
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+        const int tok = nn * tpt + tsub;
+        const bool used = tsub < tpt && tok < ntok;
+        tokn[nn] = tok;
+        rowbit[nn] = used ? (1u << tok) : 0u;
+        const int r_lo = nn * tpt, r_hi = min(nn * tpt + tpt, ntok) - 1;
+        nmask[nn] = r_lo <= r_hi ? span(r_lo, r_hi) : 0u;
+        const int64_t orow = (((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (used) raw = *(const u32x4 *)((const T *)P.Q + orow * D + 32 * s + 8 * q);
+            qf[nn][s] = __builtin_bit_cast(x8, raw);
+        }
+    }
+
+    // ---- (1) bitmaps cleared, ranges of the rows -> LDS (from the fused selector or the ranges tensor)
+    for (int i = lane; i < 2 * tpw * NW + 2 * tpw; i += 64) fullw[i] = 0u;
+    for (int r = 0; r < ntok; ++r) {
+        const int64_t row = ((int64_t)b * P.S + tw0 + r) * P.G + g;
+        int s = 0, e = 0;
+        if (P.fuse_select) {
+            const int t = SP.t_rows ? SP.t_rows[row] : SP.t0 + tw0 + r;
+            const float *pg = SP.p_grp + row * (int64_t)SP.S_sel;
+            switch (cand) {
+                case 1: select_topn_row_regs<1>(SP, pg, t, s, e); break;
+                case 2: select_topn_row_regs<2>(SP, pg, t, s, e); break;
+                case 4: select_topn_row_regs<4>(SP, pg, t, s, e); break;
+                case 8: select_topn_row_regs<8>(SP, pg, t, s, e); break;
+                default: select_topn_row_regs<16>(SP, pg, t, s, e); break;
+            }
+            if (lane < n) {
+                int32_t *out = SP.out + row * (int64_t)n * 2;
+                out[2 * lane] = s;
+                out[2 * lane + 1] = e;
+            }
+        } else if (lane < n) {
+            const int32_t *in = P.ranges + (row * n + lane) * 2;
+            s = in[0];
+            e = in[1];
+        }
+        if (lane < n) {
+            s = min(max(s, 0), P.S_kv);
+            e = min(max(e, s), P.S_kv);
+            rg[2 * (r * n + lane)] = s;
+            rg[2 * (r * n + lane) + 1] = e;
+        }
+    }
+    wave_lds_fence();
+
+    // ---- (2) block bitmaps: one (row, range) pair per lane
+    for (int p = lane; p < ntok * n; p += 64) {
+        const int r = p / n;
+        const int s = rg[2 * p], e = rg[2 * p + 1];
+        if (e > s) {
+            const int ta = s >> 6, tb = (e - 1) >> 6;          // blocks touched
+            const int fa = (s + 63) >> 6, fb = (e >> 6) - 1;   // blocks covered completely: fa..fb
+            for (int w = ta >> 5; w <= (tb >> 5); ++w) {
+                const int base = 32 * w;
+                lds_or(&touchw[r * NW + w], span(max(ta, base) - base, min(tb, base + 31) - base));
+                const int flo = max(fa, base), fhi = min(fb, base + 31);
+                if (flo <= fhi) lds_or(&fullw[r * NW + w], span(flo - base, fhi - base));
+            }
+        }
+    }
+    wave_lds_fence();
+    // union over the rows = the block schedule; kept in a register (lane w holds word w, NW <= 64)
+    unsigned u0 = 0u;
+    for (int r = 0; r < ntok; ++r)
+        if (lane < NW) u0 |= touchw[r * NW + lane];
+    unsigned long long nz0 = __ballot(u0 != 0u);
+
+    const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
+    const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
+    const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;
+    auto make_rsrc = [&](const unsigned char *base, int64_t bytes) {
+        const uint64_t a = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    [[maybe_unused]] const auto krs = make_rsrc(Kb, (int64_t)(P.S_kv - 1) * krowb + ROWB);
+    [[maybe_unused]] const auto vrs = make_rsrc(Vb, (int64_t)(P.S_kv - 1) * vrowb + ROWB);
+    [[maybe_unused]] const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
+    // one wave-wide 16-B load covers 8 rows x 128 B; the XOR swizzle sits on the SOURCE side (the DMA destination is lane-linear),
+    // and for 8-row pieces it depends on the lane only: swz_k(8 i + r) = r & 7, swz_v(8 i + r) = (r >> 1) & 3
+    const int ld_row = lane >> 3, ld_piece = lane & 7;
+    [[maybe_unused]] const uint32_t kdma = (uint32_t)(ld_row * krowb + ((ld_piece ^ (ld_row & 7)) << 4));
+    [[maybe_unused]] const uint32_t vdma = (uint32_t)(ld_row * vrowb + (((((ld_piece >> 1) ^ ((ld_row >> 1) & 3)) << 1) | (ld_piece & 1)) << 4));
+    uint32_t krd0[KS], vrd0[MT];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) krd0[s] = rho * ROWB + (((4 * s + q) ^ (rho & 7)) << 4);
+    {
+        const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) vrd0[m] = r * ROWB + ((m ^ ((r >> 1) & 3)) << 5) + 8 * pp;
+    }
+    // a block of 64 keys starting at tok0 -> wave-private LDS; rows past the end of K/V re-read the last row (they are masked:
+    // a block reaching past S_kv is never `full`)
+    auto issue_dma = [&](int tok0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);
+        if (tok0 + BLK <= P.S_kv) {
+            // K/V rows are contiguous (128 B apart: checked by the host), so 8 rows = 1 KiB on both sides: the instruction's immediate
+            // offset (added to the memory address AND to the LDS address) steps through four pieces per M0 / soffset setting
+#define NSA_BLK_DMA(RS, LP, VO, SO, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void *)((LP) + ((I) >> 2) * 4096), 16, VO, (SO) + ((I) >> 2) * 4096, ((I)&3) * 1024, 0)
+            NSA_BLK_DMA(krs, kl, kdma, ks, 0); NSA_BLK_DMA(krs, kl, kdma, ks, 1); NSA_BLK_DMA(krs, kl, kdma, ks, 2); NSA_BLK_DMA(krs, kl, kdma, ks, 3);
+            NSA_BLK_DMA(krs, kl, kdma, ks, 4); NSA_BLK_DMA(krs, kl, kdma, ks, 5); NSA_BLK_DMA(krs, kl, kdma, ks, 6); NSA_BLK_DMA(krs, kl, kdma, ks, 7);
+            NSA_BLK_DMA(vrs, vl, vdma, vs, 0); NSA_BLK_DMA(vrs, vl, vdma, vs, 1); NSA_BLK_DMA(vrs, vl, vdma, vs, 2); NSA_BLK_DMA(vrs, vl, vdma, vs, 3);
+            NSA_BLK_DMA(vrs, vl, vdma, vs, 4); NSA_BLK_DMA(vrs, vl, vdma, vs, 5); NSA_BLK_DMA(vrs, vl, vdma, vs, 6); NSA_BLK_DMA(vrs, vl, vdma, vs, 7);
+#undef NSA_BLK_DMA
+        } else {
+            const int last = P.S_kv - 1 - tok0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rc = min(8 * i + ld_row, last);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(kl + i * 1024), 16,
+                                                         rc * krowb32 + ((ld_piece ^ (ld_row & 7)) << 4), ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(vl + i * 1024), 16,
+                                                         rc * vrowb32 + (((((ld_piece >> 1) ^ ((ld_row >> 1) & 3)) << 1) | (ld_piece & 1)) << 4), vs, 0, 0);
+            }
+        }
+#else
+        (void)tok0;
+#endif
+    };
+
+    f32x4 o[NT][MT];
+    float mrun[NT], lrun[NT];
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) o[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // unused slots carry +inf so that their scores never trigger the max-raising path
+        mrun[nn] = rowbit[nn] ? -INFINITY : INFINITY;
+        lrun[nn] = 0.f;
+    }
+    const float c2 = P.scale * LOG2E;
+
+    // ---- (3) block schedule = set bits of the union bitmap, ascending (wave-uniform scalars)
+    int iw = 0;
+    unsigned ibits = 0u;
+    auto next_blk = [&]() -> int {
+        if (ibits == 0u) {
+            if (!nz0) return -1;
+            iw = __builtin_ctzll(nz0);
+            nz0 &= nz0 - 1ull;
+            ibits = (unsigned)__builtin_amdgcn_readlane((int)u0, iw);
+        }
+        const int bit = __builtin_ctz(ibits);
+        ibits &= ibits - 1u;
+        return 32 * iw + bit;
+    };
+    int cur = next_blk();
+    if (cur >= 0) issue_dma(BLK * cur);
+    int cw = -1;
+    unsigned fw = 0u, tw = 0u;
+
+    while (cur >= 0) {
+        const int nxt = next_blk();
+        const int tok0 = BLK * cur;
+        x8 kfr[4][KS];
+        x8 va[MT][2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is a vmcnt event
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kfr[u][s] = *(const x8 *)(kl + krd0[s] + u * 16 * ROWB);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const x4 lo = M::tr(vl + vrd0[m] + hf * 32 * ROWB), hi = M::tr(vl + vrd0[m] + (hf * 32 + 16) * ROWB);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[m][hf][j] = lo[j];
+                    va[m][hf][4 + j] = hi[j];
+                }
+            }
+        // ownership of this block: bit r of fullm / touchm = row r covers it completely / selected at least one of its keys
+        if ((cur >> 5) != cw) {  // lane r < ntok caches row r's bitmap words of the current 32-block group
+            cw = cur >> 5;
+            if (lane < ntok) {
+                fw = fullw[lane * NW + cw];
+                tw = touchw[lane * NW + cw];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: the buffers may be refilled
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt >= 0) issue_dma(BLK * nxt);
+        const unsigned fullm = (unsigned)__ballot((fw >> (cur & 31)) & 1u);
+        const unsigned touchm = (unsigned)__ballot((tw >> (cur & 31)) & 1u);
+        const unsigned partm = touchm & ~fullm;
+        if (partm) {  // partially covered by some row: rebuild that row's 64-key mask from its ranges
+            if (lane < 2 * tpw) kmask[lane] = 0u;
+            wave_lds_fence();
+            for (int p = lane; p < ntok * n; p += 64) {
+                const int r = p / n;
+                const int lo = max(rg[2 * p], tok0) - tok0, hi = min(rg[2 * p + 1], tok0 + BLK) - tok0;
+                if (((partm >> r) & 1u) && hi > lo) {
+                    if (lo < 32) lds_or(&kmask[2 * r], span(lo, min(hi, 32) - 1));
+                    if (hi > 32) lds_or(&kmask[2 * r + 1], span(max(lo, 32) - 32, hi - 33));
+                }
+            }
+            wave_lds_fence();
+        }
+
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            if (!(touchm & nmask[nn])) continue;  // no row of this column tile selected a key of the block
+            f32x4 sacc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sacc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) sacc[u] = M::mma(kfr[u][s], qf[nn][s], sacc[u]);
+            }
+            const bool on = (fullm & rowbit[nn]) != 0u;
+            float x[16];
+            unsigned vbits;  // bit 4u+j: key 16u + 4q + j of the block is selected by this slot's row
+            float tmax;
+            if (!(partm & nmask[nn])) {
+                // every slot is all-on or all-off: the softmax offset carries the mask (s*c2 - inf = -inf)
+                vbits = on ? 0xffffu : 0u;
+                const float mneg = on ? -mrun[nn] : -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[4 * u + j] = fmaf(sacc[u][j], c2, mneg);
+            } else {
+                unsigned lo32 = on ? 0xffffffffu : 0u, hi32 = lo32;
+                if (partm & rowbit[nn]) {
+                    lo32 = kmask[2 * tokn[nn]];
+                    hi32 = kmask[2 * tokn[nn] + 1];
+                }
+                lo32 >>= 4 * q;
+                hi32 >>= 4 * q;
+                vbits = (lo32 & 0xfu) | ((lo32 >> 12) & 0xf0u) | ((hi32 & 0xfu) << 8) | ((hi32 >> 4) & 0xf000u);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = ((vbits >> i) & 1u) ? fmaf(sacc[i >> 2][i & 3], c2, -mrun[nn]) : -INFINITY;
+            }
+            tmax = max3(max3(max3(x[0], x[1], x[2]), max3(x[3], x[4], x[5]), max3(x[6], x[7], x[8])),
+                        max3(max3(x[9], x[10], x[11]), x[12], x[13]), max3(x[14], x[15], x[15]));
+            if (__any(!(tmax <= RESCALE_THR))) {
+                float vmax = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = ((vbits >> i) & 1u) ? sacc[i >> 2][i & 3] * c2 : -INFINITY;
+                    x[i] = v;
+                    vmax = fmaxf(vmax, v);
+                }
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 16, 64));
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+                const float mnew = fmaxf(mrun[nn], vmax);
+                const float msub = (mnew == -INFINITY) ? 0.f : mnew;  // nothing valid seen yet: keep x = -inf, p = 0
+                const float alpha = (mnew == mrun[nn]) ? 1.f : __builtin_amdgcn_exp2f(mrun[nn] - msub);
+                mrun[nn] = mnew;
+                lrun[nn] *= alpha;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) o[nn][m] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] -= msub;
+            }
+            float psum = 0.f;
+            x8 pf[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pe = __builtin_amdgcn_exp2f(x[i]);
+                psum += pe;
+                pf[i >> 3][i & 7] = Elt<T>::from_f(pe);
+            }
+            lrun[nn] += psum;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                o[nn][m] = M::mma(va[m][0], pf[0], o[nn][m]);
+                o[nn][m] = M::mma(va[m][1], pf[1], o[nn][m]);
+            }
+        }
+        cur = nxt;
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+        float ltot = lrun[nn] + __shfl_xor(lrun[nn], 16, 64);
+        ltot += __shfl_xor(ltot, 32, 64);
+        if (!rowbit[nn]) continue;
+        const int64_t orow = (((int64_t)b * P.S + tw0 + tokn[nn]) * P.G + g) * h + head;
+        const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+        T *Or = (T *)P.O + orow * D;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = Elt<T>::from_f(o[nn][m][j] * inv);
+            *(x4 *)(Or + 16 * m + 4 * q) = ov;
+        }
+        if (P.lse && q == 0) P.lse[orow] = ltot > 0.f ? (mrun[nn] + __builtin_amdgcn_logf(ltot)) * LN2 : -INFINITY;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+// Column tiles per wave for a shape, 0 = not covered (the query-tile kernel takes it).  TUNE_SEL_BLOCKS: -1 auto, 0 off, N forces NT = N.
+int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int64_t kss, int64_t vss) {
+    if (!(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) || Dk != 64 || Dv != 64 || h < 1 || h > 16) return 0;
+    if (n < 1 || n > 64 || S_kv < 1 || S_kv > 131072) return 0;
+    if (kss != 64 || vss != 64) return 0;  // the DMA steps through rows 128 B apart (rows of a [.., S, 64] cache are)
+    const int mode = tuning(TUNE_SEL_BLOCKS);
+    if (mode == 0) return 0;
+    const int tpt = 16 / h;
+    int nt = (mode == 1 || mode == 2 || mode == 4) ? mode : 4;
+    while (nt > 1 && nt * tpt > 32) nt >>= 1;  // ownership masks are 32 bits wide
+    if (nt * tpt > 32) return 0;
+    while (nt > 1 && S < 2 * nt * tpt) nt >>= 1;  // short sequences: do not leave most of a wave's tiles empty
+    if (S < tpt) return 0;
+    (void)R;
+    return nt;
+}
+
+template <typename T, int NT>
+static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
+    SelAttnParams P = P0;
+    const int tpt = 16 / P.h, tpw = NT * tpt;
+    P.tpw = tpt;
+    P.nw = ((P.S_kv + 63) / 64 + 31) / 32;
+    P.nsplit = 1;
+    P.part = nullptr;
+    const int rg_ints = (2 * tpw * P.n + 3) & ~3;
+    const int bm_ints = (2 * tpw * P.nw + 2 * tpw + 3) & ~3;
+    P.wave_lds = 2 * blk::TILE_BYTES + 4 * (rg_ints + bm_ints);
+    const size_t lds = 4 * (size_t)P.wave_lds;
+    NSA_CHECK_ARG(lds <= 160 * 1024, "sel_attn_blocks: %zu B of LDS needed", lds);
+    const int64_t nbg = P.R / P.S;
+    const int64_t ngrp = (P.S + tpw - 1) / tpw;
+    const int64_t W4 = (ngrp + 3) / 4;
+    NSA_CHECK_ARG(nbg * W4 < (int64_t)1 << 31, "sel_attn_blocks: grid too large");
+    P.map_mode = (nbg % 8 == 0) ? 2 : 1;
+    SelectParams SP{};
+    int cand = 0;
+    if (P.fuse_select) {
+        NSA_CHECK_ARG(P.select != nullptr, "fused selection without selector parameters");
+        SP = *(const SelectParams *)P.select;
+        const int c = (SP.S_sel + 63) / 64;
+        NSA_CHECK_ARG(c <= 16 && SP.W <= 64 && SP.W == P.n, "fused selection: S_sel <= 1024 and at most 64 ranges per row");
+        cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
+    }
+    void (*k)(SelAttnParams, SelectParams, int) = sel_attn_blocks_mfma_kernel<T, NT>;
+    if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
+    NSA_LAUNCH_CHECK("sel_attn_blocks_mfma");
+    return NSA_OK;
+}
+
+int launch_sel_attn_blocks_mfma(const SelAttnParams &P, int dtype, int nt, hipStream_t st) {
+    if (dtype == NSA_DT_BF16) {
+        if (nt == 4) return launch_blocks_t<__bf16, 4>(P, st);
+        if (nt == 2) return launch_blocks_t<__bf16, 2>(P, st);
+        return launch_blocks_t<__bf16, 1>(P, st);
+    }
+    if (nt == 4) return launch_blocks_t<_Float16, 4>(P, st);
+    if (nt == 2) return launch_blocks_t<_Float16, 2>(P, st);
+    return launch_blocks_t<_Float16, 1>(P, st);
+}
+
+}  // namespace nsa

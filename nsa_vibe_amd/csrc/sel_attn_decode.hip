@@ -1,0 +1,43 @@
+// Decode form of the selection attention as its own launch (one 1024-thread workgroup per query row): see sel_attn_decode.hpp.
+// Used by the decode routes that do not run the fused scorer+selector+attention kernel (contexts beyond its LDS budget, other
+// score geometries, the plain nsa_sel_attn_fwd call with S = 1).
+#include "sel_attn_decode.hpp"
+
+namespace nsa {
+
+template <typename T>
+__global__ __launch_bounds__(1024) void sel_attn_decode_wg_kernel(DecAttnArgs A, const int32_t *__restrict__ ranges) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+    const int64_t row = blockIdx.x;
+    const int lane = lane_id();
+    int rs = 0, re = 0;
+    if (threadIdx.x < 64 && lane < A.n) {
+        rs = ranges[(row * A.n + lane) * 2];
+        re = ranges[(row * A.n + lane) * 2 + 1];
+    }
+    decode_attend_row<T>(A, row, rs, re, dlds);
+}
+
+bool sel_attn_decode_wg_supported(int dtype, int h, int Dk, int Dv, int n, int64_t kss, int64_t vss, const void *Q, const void *K, const void *V) {
+    if (tuning(TUNE_DECODE_WG) == 0) return false;
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16 && n >= 1 && n <= 64 && vss == 64 &&
+           kss % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0);
+}
+
+int launch_sel_attn_decode_wg(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, int64_t R, int G, int h, int S_kv, int n,
+                              int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, hipStream_t st) {
+    NSA_CHECK_ARG(R >= 1 && R < ((int64_t)1 << 31), "sel_attn_decode: bad row count");
+    NSA_CHECK_ARG((int64_t)S_kv * 128 < ((int64_t)1 << 31), "sel_attn_decode: one (b,g) V slab must be smaller than 2 GiB (buffer addressing)");
+    DecAttnArgs A{Q, K, V, O, G, h, S_kv, n, ksb, ksg, kss, vsb, vsg, vss, scale * LOG2E};
+    void (*k)(DecAttnArgs, const int32_t *) = dtype == NSA_DT_BF16 ? sel_attn_decode_wg_kernel<__bf16> : sel_attn_decode_wg_kernel<_Float16>;
+    static void *raised[2] = {nullptr, nullptr};  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
+    if (raised[0] != (void *)k && raised[1] != (void *)k) {
+        NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        (raised[0] ? raised[1] : raised[0]) = (void *)k;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)R), dim3(1024), DEC_ATT_LDS, st, A, ranges);
+    NSA_LAUNCH_CHECK("sel_attn_decode_wg");
+    return NSA_OK;
+}
+
+}  // namespace nsa

@@ -463,7 +463,11 @@ int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st) 
                   "MFMA kernel: Q/K/V must be 16-byte aligned");
     NSA_CHECK_ARG((int64_t)P.S_kv * P.kss * 2 < ((int64_t)1 << 31) && (int64_t)P.S_kv * P.vss * 2 < ((int64_t)1 << 31),
                   "MFMA kernel: one (b,g) K/V slab must be smaller than 2 GiB (buffer addressing)");
-    if (!(P.part != nullptr && P.nsplit > 1)) {  // many rows: one wave per tile of 48/h query rows, K/V tiles shared by the rows
+    if (!(P.part != nullptr && P.nsplit > 1)) {  // many rows: rows of a wave share the K/V tiles they both selected
+        if (tuning(TUNE_SEL_ROWS) < 0) {  // block form (64-key blocks, several column tiles per wave) unless a row form is forced
+            const int nb = sel_attn_blocks_nt(dtype, P.h, P.Dk, P.Dv, P.S, P.S_kv, P.n, P.R, P.kss, P.vss);
+            if (nb > 0) return launch_sel_attn_blocks_mfma(P, dtype, nb, st);
+        }
         int nt = 1;
         const int tpw = sel_attn_rows_tpw(dtype, P.h, P.Dk, P.Dv, P.S, P.S_kv, P.n, P.R, &nt);
         if (tpw > 0) return launch_sel_attn_rows_mfma(P, dtype, tpw, nt, st);

@@ -78,6 +78,10 @@ int launch_band_attn_fwd_generic(const BandAttnParams &P, int dtype, hipStream_t
 
 int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);
 int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_t st);
+// decode form (S = 1): one 1024-thread workgroup per row, partials merged through LDS (sel_attn_decode.hpp)
+bool sel_attn_decode_wg_supported(int dtype, int h, int Dk, int Dv, int n, int64_t kss, int64_t vss, const void *Q, const void *K, const void *V);
+int launch_sel_attn_decode_wg(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, int64_t R, int G, int h, int S_kv, int n,
+                              int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, hipStream_t st);
 int launch_sel_head_causal(const SelAttnParams &P, int dtype, hipStream_t st);  // parity mode of _sdpa_over_ranges
 // returns NSA_ERR_INVALID (without setting an error) when the shape is not covered
 bool sel_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
@@ -86,6 +90,9 @@ size_t sel_attn_mfma_workspace(int64_t R, int h, int Dv, int *nsplit_out);
 // query-tile form: rows per wave for this shape, 0 = not covered (use the one-row-per-wave kernel)
 int sel_attn_rows_tpw(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int *nt);
 int launch_sel_attn_rows_mfma(const SelAttnParams &P, int dtype, int tpw, int nt, hipStream_t st);
+// block form (64-key blocks, NT column tiles of 16/h rows per wave): column tiles per wave for this shape, 0 = not covered
+int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int64_t kss, int64_t vss);
+int launch_sel_attn_blocks_mfma(const SelAttnParams &P, int dtype, int nt, hipStream_t st);
 bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv);
 size_t sel_attn_bwd_mfma_workspace(int64_t R, int h, int S, int64_t nbg, int S_kv);
 int launch_sel_attn_bwd_mfma(const SelAttnBwdParams &P, int dtype, float *delta_ws, hipStream_t st);

@@ -13,6 +13,8 @@
 
 #include "nsa_common.hpp"
 #include "sel_select_row.hpp"
+#include "sel_attn_decode.hpp"
+#include "nsa_internal.hpp"
 
 namespace nsa {
 
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(64) void decode_pgrp_kernel(DecodeParams P) {
 // and select_topn_kernel (same operations, same order), so p_grp and the ranges are bit-identical to the 3-kernel route;
 // it exists because a decode step is a chain of tiny launches and each one costs ~5 us of latency.
 // ---------------------------------------------------------------------------------------
-template <typename T, int KSTEPS>
-__global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams P, SelectParams SP, int cand, int t_token) {
+template <typename T, int KSTEPS, bool ATTEND>
+__global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams P, SelectParams SP, int cand, int t_token, DecAttnArgs AT, int stop) {
     typedef typename std::conditional<std::is_same<T, __bf16>::value, bf16x8, f16x8>::type x8;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6), rho = lane & 15, q = lane >> 4;
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
             }
         }
     }
+    if (stop == 1) return;  // measurement aid (TUNE_DECODE_STOP): every thread leaves together
     __syncthreads();
     // ---- phase 2a: softmax statistics per head (one wave per head)
     for (int hh = wave; hh < P.h; hh += NW) {
@@ -507,18 +510,31 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
         }
         pg[j] = grp;
     }
+    if (stop == 2) return;
     __syncthreads();
     // ---- phase 3: top-n + forced blocks + merge (one wave)
+    int rs = 0, re = 0;
     if (wave == 0) {
         int32_t *out = SP.out + row * (int64_t)SP.W * 2;
         switch (cand) {
-            case 1: select_topn_row<1>(SP, pg, t_token, out); break;
-            case 2: select_topn_row<2>(SP, pg, t_token, out); break;
-            case 4: select_topn_row<4>(SP, pg, t_token, out); break;
-            case 8: select_topn_row<8>(SP, pg, t_token, out); break;
-            case 16: select_topn_row<16>(SP, pg, t_token, out); break;
-            default: select_topn_row<32>(SP, pg, t_token, out); break;
+            case 1: select_topn_row_regs<1>(SP, pg, t_token, rs, re); break;
+            case 2: select_topn_row_regs<2>(SP, pg, t_token, rs, re); break;
+            case 4: select_topn_row_regs<4>(SP, pg, t_token, rs, re); break;
+            case 8: select_topn_row_regs<8>(SP, pg, t_token, rs, re); break;
+            case 16: select_topn_row_regs<16>(SP, pg, t_token, rs, re); break;
+            default: select_topn_row_regs<32>(SP, pg, t_token, rs, re); break;
         }
+        if (lane < SP.W) {
+            out[2 * lane] = rs;
+            out[2 * lane + 1] = re;
+        }
+    }
+    // ---- phase 4: selection attention of the row over the ranges just chosen (same workgroup: the 16 waves take the 64-key chunks,
+    // partials merged through LDS -- sel_attn_decode.hpp).  The logits / scores in LDS are dead by now: their space holds the V tiles.
+    if constexpr (ATTEND) {
+        if (stop == 3) return;
+        __syncthreads();
+        if constexpr (KSTEPS == 2) decode_attend_row<T>(AT, row, rs, re, (unsigned char *)dsm);
     }
 }
 
@@ -538,7 +554,7 @@ bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_se
 
 int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg, int64_t css,
                                const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,
-                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st) {
+                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st, const DecAttnArgs *attend) {
     const int64_t R = (int64_t)B * G;
     NSA_CHECK_ARG(R <= 65535 * 32, "decode scorer: too many rows");
     DecodeParams P{Q, Kc, nullptr, nullptr, nullptr, csc_ptr, csc_rows, csc_vals, R, 1, G, h, Dk, S_cmp, S_sel, csb, csg, css, scale * LOG2E};
@@ -551,12 +567,18 @@ int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int 
     SP.t0 = t_token;
     const int c = (S_sel + 63) / 64;
     const int cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : c <= 16 ? 16 : 32;
-    const size_t lds = decode_fused_lds(h, S_cmp, S_sel);
-    void (*k)(DecodeParams, SelectParams, int, int);
-    if (dtype == NSA_DT_BF16) k = Dk == 64 ? decode_score_select_kernel<__bf16, 2> : decode_score_select_kernel<__bf16, 4>;
-    else k = Dk == 64 ? decode_score_select_kernel<_Float16, 2> : decode_score_select_kernel<_Float16, 4>;
+    size_t lds = decode_fused_lds(h, S_cmp, S_sel);
+    void (*k)(DecodeParams, SelectParams, int, int, DecAttnArgs, int);
+    DecAttnArgs AT{};
+    if (attend) {  // the attention of the row runs in the same launch (Dk = Dv = 64 only: checked by the caller)
+        NSA_CHECK_ARG(Dk == 64, "decode scorer: fused attention needs Dk = 64");
+        AT = *attend;
+        lds = lds > (size_t)DEC_ATT_LDS ? lds : (size_t)DEC_ATT_LDS;
+        k = dtype == NSA_DT_BF16 ? decode_score_select_kernel<__bf16, 2, true> : decode_score_select_kernel<_Float16, 2, true>;
+    } else if (dtype == NSA_DT_BF16) k = Dk == 64 ? decode_score_select_kernel<__bf16, 2, false> : decode_score_select_kernel<__bf16, 4, false>;
+    else k = Dk == 64 ? decode_score_select_kernel<_Float16, 2, false> : decode_score_select_kernel<_Float16, 4, false>;
     if (lds > 64 * 1024) {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
-        static void *raised[4] = {nullptr, nullptr, nullptr, nullptr};
+        static void *raised[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool done = false;
         for (void *r : raised) done |= (r == (void *)k);
         if (!done) {
@@ -568,9 +590,18 @@ int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int 
                 }
         }
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)R), dim3(1024), lds, st, P, SP, cand, t_token);
+    hipLaunchKernelGGL(k, dim3((unsigned)R), dim3(1024), lds, st, P, SP, cand, t_token, AT, tuning(TUNE_DECODE_STOP));
     NSA_LAUNCH_CHECK("decode_score_select");
     return NSA_OK;
+}
+
+int launch_decode_score_select_attend(const void *Q, const void *Kc, const void *K, const void *V, void *O, int B, int G, int h, int Dk, int S_cmp,
+                                      int S_kv, int64_t csb, int64_t csg, int64_t css, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
+                                      int64_t vsg, int64_t vss, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
+                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st) {
+    const DecAttnArgs AT{Q, K, V, O, G, h, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, scale * LOG2E};
+    return launch_decode_score_select(Q, Kc, B, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype,
+                                      scale, ranges_out, st, &AT);
 }
 
 size_t decode_scores_workspace(int64_t R, int h, int S_cmp) {

@@ -66,32 +66,67 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         // 32 rounds of {compare, ballot, popcount} find the k-th largest key T; everything above T is picked and the
         // remaining slots go to the keys equal to T in ascending index order -- exactly (key desc, idx asc), with no
         // cross-lane data movement (the iterative arg-max needed 12 dependent ds_bpermute per pick).
+        // The rounds COUNT on a per-lane sorted copy of the keys (descending): a round asks "are there >= k keys >= cand", so it
+        // walks the sorted slots until the count reaches k or a slot has no key >= cand -- one or two ballots instead of CAND
+        // (k = 13 of 1024 at S = 64k: slot 0, the 64 lane maxima, settles most rounds).  The picks are then made on the
+        // original keys, slot by slot in ascending index order, skipping slots without a key >= T.
         unsigned u[CAND];
-        int nv = 0;
 #pragma unroll
         for (int c = 0; c < CAND; ++c) {
             const unsigned bits = __float_as_uint(key[c]);
             const bool ok = key[c] > -INFINITY;  // forced / masked / NaN candidates never compete
             u[c] = ok ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0u;  // valid keys map to >= 0x00800000
-            nv += __popcll(__ballot(ok));
         }
-        const int k_eff = min(P.k_actual, nv);
+        constexpr bool SORTED = CAND <= 16;  // beyond 1024 blocks the sorted copy would not fit the register budget: plain counting
+        unsigned w[CAND];  // per-lane descending copy (Batcher's odd-even merge sort, CAND a power of two)
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) w[c] = u[c];
+        if constexpr (SORTED) {
+#pragma unroll
+            for (int pp = 1; pp < CAND; pp <<= 1)
+#pragma unroll
+                for (int kk = pp; kk >= 1; kk >>= 1)
+#pragma unroll
+                    for (int jj = kk % pp; jj + kk < CAND; jj += 2 * kk)
+#pragma unroll
+                        for (int ii = 0; ii < kk; ++ii)
+                            if (ii + jj + kk < CAND && (ii + jj) / (2 * pp) == (ii + jj + kk) / (2 * pp)) {
+                                const unsigned a = w[ii + jj], b = w[ii + jj + kk];
+                                w[ii + jj] = max(a, b);
+                                w[ii + jj + kk] = min(a, b);
+                            }
+        }
+        // counts are capped: only "at least k" matters to the search
+        auto count_ge = [&](unsigned cand, int cap) -> int {
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                const unsigned long long b = __ballot(w[c] >= cand);
+                if (SORTED && b == 0ull) break;
+                cnt += __popcll(b);
+                if (SORTED && cnt >= cap) break;
+            }
+            return cnt;
+        };
+        const int k_eff = min(P.k_actual, count_ge(1u, P.k_actual));  // valid candidates, as far as they matter
         if (k_eff > 0) {
             unsigned T = 0;
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned cand = T | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int c = 0; c < CAND; ++c) cnt += __popcll(__ballot(u[c] >= cand));
-                if (cnt >= k_eff) T = cand;
+                if (count_ge(cand, k_eff) >= k_eff) T = cand;
             }
-            int cnt_gt = 0;
+            int cnt_gt = 0;  // keys above T: fewer than k_eff by construction
 #pragma unroll
-            for (int c = 0; c < CAND; ++c) cnt_gt += __popcll(__ballot(u[c] > T));
+            for (int c = 0; c < CAND; ++c) {
+                const unsigned long long b = __ballot(w[c] > T);
+                if (SORTED && b == 0ull) break;
+                cnt_gt += __popcll(b);
+            }
             int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
             const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
+                if (__ballot(u[c] >= T) == 0ull) continue;
                 const bool eq = u[c] == T;
                 const unsigned long long em = __ballot(eq);
                 const int take = min(__popcll(em), remaining);

@@ -508,3 +508,142 @@ def test_g17_head_causal_parity_mode_matches_reference(nv, orc, name, dtype):
     O2 = nv.selection_attention_head_causal_parity(Q, K, cache[:, :, : V.shape[2]], r64)[:, 0]
     assert torch.equal(O, O2) and torch.equal(r64, keep)
     assert not O[0, 0].any()
+
+
+# ---- the block-form forward kernel (sel_attn_blocks_mfma.hip): NT column tiles of 16/h rows per wave, 64-key blocks ------------
+@pytest.mark.parametrize("nt", [1, 2, 4])
+@pytest.mark.parametrize("h", [1, 2, 3, 4, 5, 6, 8, 16])
+def test_block_kernel_against_oracle(nv, orc, nt, h, tune):
+    """rows of one wave with DIFFERENT selections: unaligned, overlapping and duplicate ranges (partially covered blocks incl. ones that
+    straddle the 32-key word halves of the per-row key mask), an empty row, a row covering everything, ranges ending in the last
+    (partial) block of K/V, odd S (last wave / last column tile short), S_kv not a multiple of 64"""
+    tune("SEL_ROWS", -1)
+    tune("SEL_BLOCKS", nt)
+    D = 64
+    rng = np.random.default_rng([h, nt, 77])
+    B, S, G, n, S_kv = 2, 37, 2, 9, 333
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, S, G, n, S_kv)
+    rg[0, 0, 0] = 0  # empty row
+    rg[0, 1, 0] = 0
+    rg[0, 1, 0, 0] = (0, S_kv)  # everything
+    rg[0, 2, 0, :3] = [(10, 50), (40, 70), (40, 70)]  # overlap + duplicate, crosses the block boundary at 64
+    rg[0, 3, 0, :2] = [(320, 400), (-7, 3)]  # clamped on both ends, ends in the partial last block
+    rg[1, 5, 1] = 0
+    rg[1, 5, 1, 0] = (95, 97)  # two keys: one partially covered block, upper word of its key mask
+    rg[1, 6, 1] = 0
+    rg[1, 6, 1, :2] = [(128, 192), (192, 230)]  # a full block followed by a partial one (the sequential selector's clamp at t+1)
+    rg[1, 7, 0] = 0
+    rg[1, 7, 0, :2] = [(30, 34), (60, 70)]  # straddles key 32 inside a block and the block boundary
+    for dtype in (torch.bfloat16, torch.float16):
+        run_case(nv, orc, Q, K, V, rg, dtype, variant=2)
+
+
+def test_block_kernel_long_context_and_kernel_agreement(nv, tune):
+    """S_kv = 131072 (the kernel's limit: 2048 blocks = 64 schedule words), aligned selector-like blocks + an unaligned tail range: the
+    block form, the query-tile form and the generic kernel agree; the lse is finite; beyond the limit the query-tile form takes over"""
+    rng = np.random.default_rng(321)
+    B, S, G, h, D, n, S_kv = 1, 24, 2, 6, 64, 16, 131072
+    Q = torch.from_numpy(rng.standard_normal((B, S, G, h, D), dtype=np.float32)).cuda().bfloat16()
+    K = torch.from_numpy(rng.standard_normal((B, G, S_kv, D), dtype=np.float32)).cuda().bfloat16()
+    V = torch.from_numpy(rng.standard_normal((B, G, S_kv, D), dtype=np.float32)).cuda().bfloat16()
+    st = rng.integers(0, S_kv // 64, size=(B, S, G, n)) * 64
+    rg = np.stack([st, np.minimum(st + 64, S_kv)], axis=-1).astype(np.int32)
+    rg[0, :, :, 0] = (0, 64)
+    rg[0, :, :, 1] = (S_kv - 100, S_kv)  # the very end, unaligned start
+    rg[0, 3, 1, 2] = (65500, 65600)
+    want = nv.selection_attention_hip(Q, K, V, dev(rg), variant=1).float()
+    tune("SEL_ROWS", -1)
+    for nt in (1, 4):
+        tune("SEL_BLOCKS", nt)
+        got = nv.selection_attention_hip(Q, K, V, dev(rg), variant=2, return_lse=True)
+        assert (got[0].float() - want).abs().max().item() <= 1e-2
+        assert torch.isfinite(got[1]).all()
+
+
+@pytest.mark.parametrize("mode", ["sequential", "batched"])
+def test_block_kernel_equals_other_kernels_on_selector_output(nv, mode, tune):
+    """m7c geometry, ranges from the real selector (fused in the launch): the block form (every NT) against the one-row kernel -- same
+    ranges bit for bit whichever kernel hosts the selector, outputs within rounding; S not a multiple of the rows per wave"""
+    torch.manual_seed(4)
+    B, S, G, h, D = 2, 1501, 2, 6, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    p = torch.rand(B, S, G, meta.S_sel, device="cuda")
+    tune("SEL_ROWS", 0)
+    ref = nv.select_and_attend(p, Q, K, V, meta, 16, mode=mode, scale=0.125, return_lse=True)
+    tune("SEL_ROWS", -1)
+    for nt in (1, 2, 4):
+        tune("SEL_BLOCKS", nt)
+        got = nv.select_and_attend(p, Q, K, V, meta, 16, mode=mode, scale=0.125, return_lse=True)
+        assert torch.equal(got[0], ref[0])
+        assert (got[1].float() - ref[1].float()).abs().max().item() <= 2e-2
+        fin = torch.isfinite(ref[2])
+        assert torch.equal(torch.isfinite(got[2]), fin) and (got[2][fin] - ref[2][fin]).abs().max().item() <= 2e-2
+        sep = nv.selection_attention_hip(Q, K, V, got[0], scale=0.125)  # ranges tensor instead of the fused selector: same kernel, same result
+        assert torch.equal(sep, got[1])
+
+
+def test_block_kernel_forced_max_raise_at_chosen_blocks(nv, orc, tune):
+    """the deferred-max branch is data dependent: spike one key per chosen block against one query head so that the running max has
+    to be raised (and O / l rescaled) at the 1st, a middle and the last block of a row, in a column tile whose other row does NOT
+    own that block (off slots must stay untouched by the rescale of their neighbours)"""
+    tune("SEL_ROWS", -1)
+    tune("SEL_BLOCKS", 4)
+    rng = np.random.default_rng(99)
+    B, S, G, h, D, S_kv = 1, 16, 1, 6, 64, 1024
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32) * 0.3
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    rg = np.zeros((B, S, G, 4, 2), np.int32)
+    for t in range(S):
+        blocks = [0, 3 + (t % 5), 9, 15] if t % 2 == 0 else [1, 4, 9, 12]
+        rg[0, t, 0] = [(64 * j, 64 * j + 64) for j in blocks]
+    for t, blk_, head, gain in ((0, 0, 0, 6.0), (0, 9, 2, 14.0), (0, 15, 2, 30.0), (3, 12, 5, 25.0), (6, 4, 1, 18.0)):
+        key = 64 * blk_ + 17
+        K[0, 0, key] = Q[0, t, 0, head] * gain / np.sqrt(D) * 8 / np.linalg.norm(Q[0, t, 0, head])
+    for dtype in (torch.bfloat16, torch.float16):
+        run_case(nv, orc, Q, K, V, rg, dtype, variant=2, tol=2e-2)
+
+
+# ---- the decode form (sel_attn_decode.hpp): one 1024-thread workgroup per row, partials merged through LDS --------------------
+@pytest.mark.parametrize("h", [1, 3, 6, 8, 16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_decode_workgroup_kernel_against_oracle(nv, orc, h, dtype, tune):
+    """S = 1 rows with arbitrary ranges: unaligned, overlapping, duplicate and inverted ranges, an empty row, one key, a range that
+    covers everything (more 64-key chunks than the workgroup has waves: waves loop and merge their own chunks first), the tail
+    of K/V, a strided cache view; and the split-KV route (DECODE_WG = 0) gives the same result within rounding"""
+    rng = np.random.default_rng([h, 5])
+    B, G, D, n, S_kv = 7, 2, 64, 16, 3000
+    Q = rng.standard_normal((B, 1, G, h, D), dtype=np.float32)
+    K = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_kv, D), dtype=np.float32)
+    rg = _rand_ranges(rng, B, 1, G, n, S_kv)
+    rg[0, 0, 0] = 0  # empty row
+    rg[1, 0, 0] = 0
+    rg[1, 0, 0, 0] = (0, S_kv)  # everything: 47 chunks
+    rg[1, 0, 1, :3] = [(10, 50), (40, 70), (40, 70)]  # overlap + duplicate
+    rg[2, 0, 0] = 0
+    rg[2, 0, 0, 0] = (2999, 3000)  # one key, the last one
+    rg[2, 0, 1, :3] = [(2900, 3100), (-5, 3), (700, 600)]  # clamped on both ends, inverted
+    rg[3, 0, 0] = [(64 * j, 64 * j + 64) for j in (0, 3, 4, 9, 12, 13, 14, 20, 21, 25, 30, 33, 38, 40, 44, 45)]  # selector-like
+    rg[3, 0, 0, -1] = (64 * 45, 64 * 45 + 17)  # clamp at t+1
+    qd, kd, vd, rd = dev(Q, dtype), dev(K, dtype), dev(V, dtype), dev(rg)
+    tune("DECODE_WG", -1)
+    O = nv.selection_attention_hip(qd, kd, vd, rd)
+    ref = orc.sel_attention_masked(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), rg)
+    assert np.abs(O.float().cpu().numpy() - ref).max() <= TOL[dtype]
+    assert not O[0, 0, 0].any()
+    cache = torch.zeros(B, G, S_kv + 77, D, device="cuda", dtype=dtype)
+    cache[:, :, :S_kv] = vd
+    kcache = torch.zeros(B, G, S_kv + 77, D, device="cuda", dtype=dtype)
+    kcache[:, :, :S_kv] = kd
+    assert torch.equal(nv.selection_attention_hip(qd, kcache[:, :, :S_kv], cache[:, :, :S_kv], rd), O)  # strided views, bitwise
+    assert torch.equal(nv.selection_attention_hip(qd, kd, vd, rd), O)  # fixed merge order: run-to-run reproducible
+    tune("DECODE_WG", 0)
+    O_split = nv.selection_attention_hip(qd, kd, vd, rd)
+    assert (O_split.float() - O.float()).abs().max().item() <= TOL[dtype]

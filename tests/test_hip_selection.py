@@ -412,3 +412,34 @@ def test_per_step_scorer_names_and_verifiers(nv, orc, monkeypatch):
     monkeypatch.setenv("NSA_VALIDATE_SELECTION_DETERMINISM", "1")
     p_grp = nv.map_pcmp_to_pgrp(p, meta)
     assert nv.validate_selection_determinism(p_grp, meta, 8, S - 1)
+
+
+@pytest.mark.parametrize("S,n_top", [(4096, 16), (16384, 16), (65536, 16), (65536, 40), (2048, 5), (700, 16)])
+def test_selector_tie_heavy_scores_match_oracle(nv, orc, S, n_top):
+    """the threshold select counts on per-lane SORTED keys and picks on the original ones: exact ties are where that can go wrong.
+    Scores quantised to a few levels (hundreds of exact ties at the threshold, resolved by ascending block index), all-equal rows,
+    rows with fewer valid candidates than picks, zeros (negative ranking keys) and NaN candidates; both selector modes, every
+    candidates-per-lane instantiation up to 16; bit-exact against the oracle (order: key descending, index ascending)"""
+    rng = np.random.default_rng([S, n_top])
+    mo = orc.build_block_meta(S, 32, 16, 64, n_top, 512)
+    m = nv.build_block_meta(S, 32, 16, 64, n_top, 512)
+    rows = 192
+    ts = np.sort(rng.choice(S, rows, replace=False)).astype(np.int32)
+    ts[:4] = (0, 63, 64, 129)
+    ts[-1] = S - 1
+    p = np.floor(rng.random((rows, 2, m.S_sel), dtype=np.float32) * 4.0) / 4.0  # 4 levels
+    p[5] = 1.0  # everything equal
+    p[6] = 0.0  # keys are -idx*1e-8: negative floats
+    p[7, :, ::3] = np.nan  # NaN candidates never compete
+    p[8:40] = (np.floor(rng.random((32, 2, m.S_sel), dtype=np.float32) * 64.0) / 64.0).astype(np.float32)
+    p[40:60] = rng.random((20, 2, m.S_sel), dtype=np.float32)  # no ties
+    p[60:70, :, : m.S_sel // 2] = 0.5  # one long plateau next to random values
+    ref = orc.select_topn_ranges_rows(p.reshape(-1, m.S_sel), np.repeat(ts, 2), mo, n_top, True, 2)
+    full = np.zeros((1, S, 2, m.S_sel), np.float32)
+    full[0, ts] = p
+    out = nv.select_topn_ranges_rows(dev(full), m, n_top, 0, True, 2).cpu().numpy()[0, ts].reshape(-1, n_top, 2)
+    assert norm(out) == norm(ref)
+    if S <= 16384:  # batched mode on whole sequences (the oracle walks every row)
+        refb = orc.select_topn_ranges_batched(full, mo, n_top, S)
+        outb = nv.select_topn_ranges_batched(dev(full), m, n_top, S).cpu().numpy()
+        assert np.array_equal(outb, refb)
