@@ -32,8 +32,9 @@ constexpr int DEC_ATT_TAIL = ((SEG_INTS * 4 + 15) / 16) * 16;  // sorted segment
 constexpr int DEC_ATT_LDS = DEC_ATT_WAVES * DEC_ATT_TILE + DEC_ATT_TAIL;
 
 // lds: DEC_ATT_LDS bytes, 16-byte aligned; lanes i < n of wave 0 pass range i in (rs, re) (unclamped); every thread of the
-// 1024-thread workgroup must call (two workgroup barriers inside).
-template <typename T>
+// 1024-thread workgroup must call (two workgroup barriers inside).  SORTED: the ranges are ascending and disjoint with the live ones
+// first (what select_topn_row_regs emits): the sort / union pass is skipped, only the clamp to [0, S_kv] remains.
+template <typename T, bool SORTED = false>
 __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t row, int rs, int re, unsigned char *lds) {
     using M = MfmaT<T>;
     using x8 = typename M::x8;
@@ -56,21 +57,34 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
         if (rho < h) raw = *(const u32x4 *)((const T *)A.Q + (row * h + rho) * 64 + 32 * s + 8 * q);
         qf[s] = __builtin_bit_cast(x8, raw);
     }
-    if (wave == 0) {
-        int nseg;
-        const int total = normalise_ranges_lanes(rs, re, A.n, A.S_kv, seg, &nseg);
-        if (lane == 0) {
-            seg[SEG_INTS - 2] = nseg;
-            seg[SEG_INTS - 1] = total;
+    int nseg, sstart = 0, slen = 0;  // chunk table in registers: lane i holds segment i (start, length)
+    if constexpr (SORTED) {
+        if (wave == 0 && lane < A.n) {
+            const int s = min(max(rs, 0), A.S_kv), e = min(max(re, s), A.S_kv);
+            seg[2 * lane] = s;
+            seg[2 * lane + 1] = e - s;
         }
-    }
-    __syncthreads();
-    const int nseg = uniform(seg[SEG_INTS - 2]);  // wave uniform by construction: tell the compiler (scalar loop control below)
-    // chunk table in registers: lane i holds segment i (start, chunks, first chunk index)
-    int sstart = 0, slen = 0;
-    if (lane < nseg) {
-        sstart = seg[2 * lane];
-        slen = seg[2 * lane + 3] - seg[2 * lane + 1];
+        __syncthreads();
+        nseg = A.n;
+        if (lane < nseg) {
+            sstart = seg[2 * lane];
+            slen = seg[2 * lane + 1];
+        }
+    } else {
+        if (wave == 0) {
+            int ns;
+            const int total = normalise_ranges_lanes(rs, re, A.n, A.S_kv, seg, &ns);
+            if (lane == 0) {
+                seg[SEG_INTS - 2] = ns;
+                seg[SEG_INTS - 1] = total;
+            }
+        }
+        __syncthreads();
+        nseg = uniform(seg[SEG_INTS - 2]);  // wave uniform by construction: tell the compiler (scalar loop control below)
+        if (lane < nseg) {
+            sstart = seg[2 * lane];
+            slen = seg[2 * lane + 3] - seg[2 * lane + 1];
+        }
     }
     const int nck = (slen + 63) >> 6;
     int inc = nck;

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
     if constexpr (ATTEND) {
         if (stop == 3) return;
         __syncthreads();
-        if constexpr (KSTEPS == 2) decode_attend_row<T>(AT, row, rs, re, (unsigned char *)dsm);
+        if constexpr (KSTEPS == 2) decode_attend_row<T, true>(AT, row, rs, re, (unsigned char *)dsm);
     }
 }
 

@@ -48,7 +48,11 @@ struct MfmaS<_Float16> {
     __device__ static f32x4 mma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T, int D, int NT>
+// HC: heads per group as a compile-time constant (0 = read P.h at run time).  The Eq.10 head sum is h - 1 DPP adds per
+// (16-row sub-tile, column tile); with a run-time h every one of the 15 possible adds is its own two-instruction basic block
+// behind a scalar compare and branch (16 blocks x 16 sub-tiles per K_cmp tile: the second sweep cost 2.4x the first per tile,
+// profiles/r01 e_pmc: 543 vs 222 VALU per wave and tile), with HC the sum is straight-line code.
+template <typename T, int D, int NT, int HC>
 __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     using M = MfmaS<T>;
     using x8 = typename M::x8;
@@ -64,12 +68,14 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     const int lane = tid & 63;
     const int wave = uniform(tid >> 6);
     const int rho = lane & 15, q = lane >> 4;
-    const int h = P.h;
+    const int h = HC ? HC : P.h;
     const int QPT = 16 / h;              // queries per 16-column tile
     const int QW = 4 * NT * QPT;         // queries per workgroup
     const int bg = blockIdx.y;
     const int b = bg / P.G, g = bg % P.G;
-    const int t0 = blockIdx.x * QW;
+    // late query tiles first: with causal_skip the second sweep of a tile grows with its position (a tile at the end of a 64k sequence does
+    // 1.5x the work of the first one), and the dispatcher hands out workgroups in index order -- longest first keeps the tail short
+    const int t0 = (P.causal_skip ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QW;
     const T *Kc = (const T *)P.Kc + (int64_t)b * P.csb + (int64_t)g * P.csg;
     const float c2 = P.scale * LOG2E;
 
@@ -268,7 +274,12 @@ static int launch_scores_t(const ScoresMfmaParams &P, hipStream_t st) {
     const int QPT = 16 / P.h;
     const int QW = 4 * NT * QPT;
     dim3 grid((unsigned)((P.S + QW - 1) / QW), (unsigned)(P.B * P.G));
-    hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT>), grid, dim3(256), 0, st, P);
+    switch (P.h) {  // the common group sizes get straight-line head sums
+        case 6: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 6>), grid, dim3(256), 0, st, P); break;
+        case 4: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 4>), grid, dim3(256), 0, st, P); break;
+        case 8: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 8>), grid, dim3(256), 0, st, P); break;
+        default: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 0>), grid, dim3(256), 0, st, P); break;
+    }
     NSA_LAUNCH_CHECK("scores_mfma");
     return NSA_OK;
 }

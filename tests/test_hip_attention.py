@@ -647,3 +647,33 @@ def test_decode_workgroup_kernel_against_oracle(nv, orc, h, dtype, tune):
     tune("DECODE_WG", 0)
     O_split = nv.selection_attention_hip(qd, kd, vd, rd)
     assert (O_split.float() - O.float()).abs().max().item() <= TOL[dtype]
+
+
+def test_backward_properties_at_config5_size(nv):
+    """BASELINE config 5 shape of the selected branch (m7c, S = 4096, B = 8, bf16, ranges from the batched selector): the backward at
+    full size is finite, bitwise reproducible (no atomics), exactly linear in dO (scaling dO by 2 is exact in every product), leaves
+    zero dK / dV on keys no row selected (the cache is longer than the selected prefix) and zero dQ on rows without a token"""
+    torch.manual_seed(11)
+    B, S, G, h, D, n = 8, 4096, 2, 6, 64, 16
+    S_kv = S + 512
+    meta = nv.build_block_meta(S, 32, 16, 64, n, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S_kv, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S_kv, D, device="cuda").bfloat16()
+    dO = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, n, S)
+    assert not rg[:, :63].any()  # batched mode: rows before the first complete block select nothing
+
+    def grads(d):
+        q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+        nv.selection_attention_hip(q, k, v, rg).backward(d)
+        return q.grad, k.grad, v.grad
+
+    g1, g1b, g2 = grads(dO), grads(dO), grads(dO * 2)
+    for a, b_, c in zip(g1, g1b, g2):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b_)  # reproducible
+        assert torch.equal(a.float() * 2, c.float())  # linear in dO (a power-of-two factor is exact)
+    assert not g1[1][:, :, S:].any() and not g1[2][:, :, S:].any()  # keys beyond every range: never hit
+    assert not g1[0][:, :63].any()  # rows without a token
+    assert g1[1][:, :, :S].abs().amax(dim=(2, 3)).min().item() > 0 and g1[0][:, 64:].abs().amax(dim=(2, 3, 4)).min().item() > 0

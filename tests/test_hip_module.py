@@ -693,3 +693,65 @@ def test_native_paths_refuse_a_mismatched_cache():
         _, kv = m(x, kv, prefill=True)
         with pytest.raises(RuntimeError, match="does not match the input"):
             m(x[:1, :1], kv, prefill=False)
+
+
+def test_m7c_layer_at_config3_size(orc, monkeypatch):
+    """BASELINE config 3: the whole m7c NSAAttention layer (cmp + sel + win + gate, dim 768, 12 heads, G 2, d 64, l 32, d 16, l' 64,
+    n 16, w 512) at S = 16384, bf16: native prefill (one native call between the two GEMMs) + 64 decode steps (one native call each)
+    against the eager composition of the same layer (torch projections / RoPE / pooling / gate around the attention kernels), and
+    the selected ranges of sampled prefill rows against the oracle chain on the layer's own Q / K_cmp (gap-gated exactness)."""
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    torch.manual_seed(3)
+    S, n_dec, B = 16384, 64, 1
+    m = NSAAttention(768, 12, 2, 64, 64, l=32, d=16, l_sel=64, n_sel=16, w=512, selector="batched").cuda().bfloat16().eval()
+    x = torch.randn(B, S + n_dec, 768, device="cuda", dtype=torch.bfloat16)
+    outs = {}
+    for mode in ("native", "eager"):
+        kv = m.new_kv(B, S + n_dec, "cuda", torch.bfloat16)
+        if mode == "eager":
+            monkeypatch.setenv("NSA_HIP_EAGER_TRAIN", "1")
+        with torch.set_grad_enabled(mode == "eager"):
+            assert m._native_ok(x) == (mode == "native")
+            o, kv = m(x[:, :S], kv, prefill=True)
+            rng_prefill = m._last_ranges.clone()
+            dec = []
+            for t in range(S, S + n_dec):
+                y, kv = m(x[:, t: t + 1], kv, prefill=False)
+                dec.append(y.detach())
+        outs[mode] = (o.detach().float(), torch.cat(dec, dim=1).float(), kv, rng_prefill)
+    na, ea = outs["native"], outs["eager"]
+    assert na[2].t == ea[2].t == S + n_dec and na[2].n_cmp == ea[2].n_cmp == (S + n_dec - 32) // 16 + 1
+    for name in ("K_sel", "V_sel", "K_win", "V_win", "K_cmp", "V_cmp"):
+        assert (getattr(na[2], name).float() - getattr(ea[2], name).float()).abs().max().item() <= 4e-2, name
+    for a, e in ((na[0], ea[0]), (na[1], ea[1])):
+        err = (a - e).abs().amax(dim=-1)
+        assert torch.isfinite(a).all()
+        # bf16 end to end: a near-tie selection can flip between the two arithmetic orders; bound the typical row and the tail
+        assert err.median().item() <= 3e-2 and (err <= 8e-2).float().mean().item() >= 0.97
+    same = (na[3] == ea[3]).all(dim=-1).all(dim=-1).float().mean().item()
+    assert same >= 0.97  # rows of [B,S,G] whose ranges agree between the two paths
+    # ---- sampled prefill rows against the oracle chain on the layer's own (bf16) Q and K_cmp
+    from nsa_vibe_amd.nsa_attention import apply_rope
+
+    ts = np.unique(np.concatenate([np.arange(60, 200, 7), np.arange(1000, S, 997), np.arange(S - 40, S)])).astype(np.int64)
+    with torch.no_grad():
+        Qs = apply_rope(m.W_Q(x[:, ts]), torch.from_numpy(ts).cuda()).view(B, len(ts), 2, 6, 64)
+    kvn = na[2]
+    Kc = kvn.K_cmp[:, :, : (S - 32) // 16 + 1]
+    om = orc.build_block_meta(S, 32, 16, 64, 16, 512)
+    p_cmp = orc.compute_pcmp_all(Qs.float().cpu().numpy(), Kc.float().cpu().numpy(), 0.125)
+    _, pg = orc.map_pcmp_to_pslc_and_pgrp(p_cmp[0], om)  # [rows, G, S_sel]
+    full = np.zeros((1, S, 2, om.sel_starts.size), np.float32)
+    full[0, ts] = pg
+    r_ref = orc.select_topn_ranges_batched(full, om, 16, S)[0, ts].reshape(-1, 16, 2)
+    got = na[3][0, torch.from_numpy(ts).cuda()].cpu().numpy().reshape(-1, 16, 2)
+    from test_hip_selection import _topn_gap
+
+    gaps = _topn_gap(pg.reshape(-1, om.sel_starts.size), ts.astype(np.int32))
+    gated = gaps > 2e-5  # the layer's Q went through one more bf16 rounding (RoPE) than the oracle's: a wider gate
+    same_rows = (got == r_ref).all(axis=(-1, -2))
+    print(f"config 3 layer: sampled rows {gated.size}, gated {int(gated.sum())}, mismatching rows overall {1 - same_rows.mean():.4f}")
+    # random weights give nearly uniform group scores (most 13th / 14th gaps sit below the gate): the gate must still hold rows, every
+    # gated row has to agree, and the ungated flips stay a small minority
+    assert gated.mean() > 0.3 and same_rows[gated].mean() >= 0.98 and same_rows.mean() >= 0.95
