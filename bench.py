@@ -14,11 +14,12 @@ Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequence
 path (weak scaling); time = max over ranks.
 
 The JSON line also carries
-  roofline         dominant kernel of the step (select + attend, one launch).  In prefill every K/V row is gathered ~L/S*n
-                   times, so the gather is served by L2 / Infinity Cache and is NOT an HBM stream: the roof that bounds the
-                   in-block QK^T / PV work is the dense bf16 MFMA peak (bound "mfma": algorithmic flops 4*h*L*D per row over
-                   HIP-event kernel time vs 2.5 PFLOP/s); the gathered bytes vs the aggregate L2 bandwidth and the PMC HBM
-                   traffic per launch (profiles/r02/traffic_*.json) are reported beside it.
+  roofline         dominant kernel of the step (select + attend, one launch).  In prefill every K/V row is gathered many times:
+                   at S=65536 a (b,g)'s K/V (16 MiB) exceeds an XCD's 4 MiB L2, a third of the gathered bytes miss, and the launch is
+                   bound by that L2-miss traffic -- bound "hbm": HBM-side bytes per launch (rocprofv3 PMC, profiles/r02/traffic_*.json,
+                   same shape) / HIP-event kernel time vs the 8 TB/s peak.  The algorithmic gather rate (> peak: cache reuse), the
+                   gathered bytes vs the aggregate L2 bandwidth (`l2`) and the in-block MFMA fraction (`mfma`) sit beside it.  Shapes
+                   whose K/V fits L2 (S <= 16k) report bound "l2".
   decode_roofline  the HBM-bound configuration north_star names: one decode step of B sequences at context S reads
                    sum_rows L_row*(Dk+Dv)*2 B of selected K/V plus the compressed keys (S_cmp*Dk*2 B per (b,g)) exactly once
                    (reads formula of nsa/core/nsa_attention.py:634-635, bytes formula of triton_sel_kernel/__init__.py:483);
@@ -621,19 +622,32 @@ def main():
         flops = 4.0 * H * Lsum * D  # 2*h*L*Dk (QK^T) + 2*h*L*Dv (PV) per row
         tfl = flops / (t_att * 1e-3) / 1e12
         traffic = pmc_traffic(f"S{S}_B{B}")
-        out["roofline"] = {
-            "kernel": "select + attend (one launch: top-n selection of the row, then its block-sparse attention)", "bound": "mfma",
-            "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-            "qk_frac": 0.5 * tfl / MFMA_BF16_PEAK_TFLOPS,
-            "why_not_hbm": "prefill gathers every K/V row many times (algorithmic gather below vs the unique K/V above): the gather is served "
-                           "by L2 / Infinity Cache, PMC HBM traffic per launch is `traffic`; the HBM-bound configuration is decode_roofline",
-            "algorithmic_flops_per_launch": flops, "algorithmic_gather_bytes_per_launch": alg_bytes,
-            "gathered_bytes_per_launch": gathered, "gather_GBps": gathered / (t_att * 1e-3) / 1e9, "l2_peak": L2_PEAK_GBPS,
-            "l2_frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS,
-            "l2_note": "gathered = the K/V tiles really brought into LDS (rows of one wave share a tile they both selected) vs the ~34.5 TB/s "
-                       "aggregate L2 bandwidth of the guide; algorithmic = the per-row figure of SURVEY 8(d)",
-            "kernel_ms": t_att, "mean_selected_tokens_per_row": Lmean,
-            "hbm_traffic_frac_of_peak": (traffic / (t_att * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None}
+        mfma = {"bound": "mfma", "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS,
+                "qk_frac": 0.5 * tfl / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                "note": "in-block QK^T + PV flops 4*h*L*D per row over the same kernel time: the matrix pipe is far from binding here"}
+        l2 = {"bound": "l2", "achieved": gathered / (t_att * 1e-3) / 1e9, "peak": L2_PEAK_GBPS, "unit": "GB/s",
+              "frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS, "gathered_bytes_per_launch": gathered,
+              "note": "K/V tiles really brought into LDS (rows of one wave share a tile they both selected) vs the ~34.5 TB/s aggregate "
+                      "L2 bandwidth of the guide"}
+        common = {"kernel": "select + attend (one launch: top-n selection of the row, then its block-sparse attention)", "kernel_ms": t_att,
+                  "mean_selected_tokens_per_row": Lmean, "algorithmic_gather_bytes_per_launch": alg_bytes,
+                  "algorithmic_gather_GBps": alg_bytes / (t_att * 1e-3) / 1e9, "traffic": traffic}
+        if traffic is not None and traffic > 0.1 * gathered:
+            # the launch is bound by what leaves the L2s: a (b,g)'s K/V (16 MiB at 64k) does not fit the 4 MiB of an XCD's L2, a third of
+            # the gathered bytes miss and travel over the fabric (Infinity Cache / HBM).  achieved = those bytes (PMC) / live kernel time.
+            ach = traffic / (t_att * 1e-3) / 1e9
+            out["roofline"] = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS,
+                                   frac_of_measured_stream_rate=ach / 6290.0,
+                                   note="achieved = HBM-side bytes of the launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per the MI355X guide, "
+                                        "profiles/r02/traffic_*.json, same shape) / HIP-event kernel time.  The ALGORITHMIC gather (sum_rows L_row*256 B, "
+                                        "SURVEY 8(d)) is re-read ~S*n*l'/S_kv times per K/V row and is served mostly by L2 (algorithmic_gather_GBps "
+                                        "exceeds every memory roof): what binds is the L2-miss traffic, at the rate a streaming copy reaches "
+                                        "(6.29 TB/s measured in the guide = frac_of_measured_stream_rate)",
+                                   l2=l2, mfma=mfma)
+        else:
+            out["roofline"] = dict(common, **{k: v for k, v in l2.items() if k != "note"},
+                                   note="K/V of a (b,g) fits its XCD's L2: the gather is L2 resident (PMC HBM traffic = `traffic`, ~compulsory), the launch "
+                                        "is bound by instruction issue and the L1->LDS path; see DESIGN 4.1c", mfma=mfma)
         out["stages_ms"] = {"scores": t_sc, "select_and_attention_one_launch": t_att, "select_standalone_kernel": t_sel,
                             "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
                                     "so scores + select_and_attention can exceed it slightly.  select_standalone_kernel is not part of the step"}
@@ -665,7 +679,8 @@ def main():
                                                     "attn_gathered_GBps": nt2 * 32 * 256 / (at * 1e-3) / 1e9,
                                                     "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12,
                                                     "attn_mfma_frac": 4.0 * H * Ls * D / (at * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                                    "hbm_traffic": pmc_traffic(f"S{S2}_B{B2}")}
+                                                    "hbm_traffic": pmc_traffic(f"S{S2}_B{B2}"),
+                                                    "hbm_traffic_frac_of_peak": (pmc_traffic(f"S{S2}_B{B2}") or 0.0) / (at * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                     if S2 == 4096 and B2 == 8:
                         extra[f"sel_attn_fwd_bwd_S{S2}_B{B2}"] = backward_bench(nv, m2, Q2, K2, V2, S2)
                     del m2, Q2, Kc2, K2, V2

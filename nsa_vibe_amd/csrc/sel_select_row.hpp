@@ -96,7 +96,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                                 w[ii + jj + kk] = min(a, b);
                             }
         }
-        // counts are capped: only "at least k" matters to the search
+        // counts are capped just above k: the search needs "at least k", and "exactly k" ends it early
         auto count_ge = [&](unsigned cand, int cap) -> int {
             int cnt = 0;
 #pragma unroll
@@ -104,34 +104,48 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                 const unsigned long long b = __ballot(w[c] >= cand);
                 if (SORTED && b == 0ull) break;
                 cnt += __popcll(b);
-                if (SORTED && cnt >= cap) break;
+                if (SORTED && cnt > cap) break;  // exact while <= cap
             }
             return cnt;
         };
         const int k_eff = min(P.k_actual, count_ge(1u, P.k_actual));  // valid candidates, as far as they matter
         if (k_eff > 0) {
+            // MSB-first search for the k-th largest key T.  A prefix with EXACTLY k keys at or above it ends the search: those k keys
+            // are the picks whatever the remaining bits are (no tie can straddle the cut) -- typically after ~20 of the 32 rounds.
             unsigned T = 0;
+            bool exact = false;
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned cand = T | (1u << bit);
-                if (count_ge(cand, k_eff) >= k_eff) T = cand;
+                const int c = count_ge(cand, k_eff);
+                if (c >= k_eff) T = cand;
+                if (c == k_eff) {
+                    exact = true;
+                    break;
+                }
             }
-            int cnt_gt = 0;  // keys above T: fewer than k_eff by construction
+            if (exact) {
 #pragma unroll
-            for (int c = 0; c < CAND; ++c) {
-                const unsigned long long b = __ballot(w[c] > T);
-                if (SORTED && b == 0ull) break;
-                cnt_gt += __popcll(b);
-            }
-            int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
-            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+                for (int c = 0; c < CAND; ++c)
+                    if (u[c] >= T) selbits |= 1ull << c;
+            } else {
+                int cnt_gt = 0;  // keys above T: fewer than k_eff by construction
 #pragma unroll
-            for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
-                if (__ballot(u[c] >= T) == 0ull) continue;
-                const bool eq = u[c] == T;
-                const unsigned long long em = __ballot(eq);
-                const int take = min(__popcll(em), remaining);
-                if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1ull << c;
-                remaining -= take;
+                for (int c = 0; c < CAND; ++c) {
+                    const unsigned long long b = __ballot(w[c] > T);
+                    if (SORTED && b == 0ull) break;
+                    cnt_gt += __popcll(b);
+                }
+                int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
+                const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
+                    if (__ballot(u[c] >= T) == 0ull) continue;
+                    const bool eq = u[c] == T;
+                    const unsigned long long em = __ballot(eq);
+                    const int take = min(__popcll(em), remaining);
+                    if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1ull << c;
+                    remaining -= take;
+                }
             }
         }
     }
