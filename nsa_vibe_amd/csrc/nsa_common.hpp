@@ -42,6 +42,7 @@ enum Tune {
     TUNE_DECODE_UNFUSED,    // NSA_HIP_DECODE_UNFUSED: 1 = three-kernel decode scorer route
     TUNE_SEL_BLOCKS,        // NSA_HIP_SEL_BLOCKS: 64-key block form of the selection forward, -1 auto, 0 off, N = row pairs per wave
     TUNE_DECODE_WG,         // NSA_HIP_DECODE_WG: decode attention as one workgroup per row (+ fused into the decode scorer), -1 auto, 0 off
+    TUNE_SEL_ROWSUM,        // NSA_HIP_SEL_ROWSUM: block-form forward, row sums of P by MFMA (1) or by v_add (0)
     TUNE_DECODE_STOP,       // NSA_HIP_DECODE_STOP: measurement aid, the fused decode kernel returns after phase N (1 logits, 2 scores, 3 top-n); 0 = run all
     TUNE_COUNT
 };

@@ -21,7 +21,7 @@ int sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, const 
                          size_t workspace_bytes, void *stream, int defer, int *ns_used, float **part_used);
 
 bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_sel, int64_t csb, int64_t csg, int64_t css, const void *Q,
-                                   const void *Kc);
+                                   const void *Kc, int64_t rows);
 struct DecAttnArgs;  // sel_attn_decode.hpp: non-null = the row's selection attention runs in the same launch
 int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg, int64_t css,
                                const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,

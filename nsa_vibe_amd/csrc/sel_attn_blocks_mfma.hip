@@ -41,7 +41,9 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 }
 }  // namespace blk
 
-template <typename T, int NT>
+// RS: row sums of P on the matrix pipe (l += ones . P^T: 2 MFMAs per tile instead of 16 v_add; the pipe is ~18 % busy, the VALU is the
+// bound) -- the sum then runs over the bf16 P the PV product uses, and every lane holds the whole column sum (no cross-lane step at the end)
+template <typename T, int NT, bool RS>
 __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     using namespace blk;
     using M = MfmaT<T>;
@@ -80,16 +82,17 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     // ---- per-slot constants; the Q loads go out first so that their latency runs under the range / bitmap work below
     const int rho = lane & 15, q = lane >> 4;
     const int tsub = rho / h, head = rho - tsub * h;  // row inside the column tile, head
-    int tokn[NT];
-    unsigned rowbit[NT];  // bit of the slot's row in the ownership masks, 0 for an unused slot
+    // bit of the slot's row in the ownership masks (0 for an unused slot) = (tsbit << nn*tpt) & usedmask: two VALU ops where it is needed
+    // instead of NT registers (the kernel sits at the 256-VGPR budget)
+    const unsigned tsbit = tsub < tpt ? (1u << tsub) : 0u;
+    const unsigned usedmask = span(0, ntok - 1);
+    auto rowbit = [&](int nn) -> unsigned { return (tsbit << (nn * tpt)) & usedmask; };
     unsigned nmask[NT];   // rows of column tile nn (wave uniform)
     x8 qf[NT][KS];
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
         const int tok = nn * tpt + tsub;
         const bool used = tsub < tpt && tok < ntok;
-        tokn[nn] = tok;
-        rowbit[nn] = used ? (1u << tok) : 0u;
         const int r_lo = nn * tpt, r_hi = min(nn * tpt + tpt, ntok) - 1;
         nmask[nn] = r_lo <= r_hi ? span(r_lo, r_hi) : 0u;
         const int64_t orow = (((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head;
@@ -221,10 +224,13 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
 #pragma unroll
         for (int m = 0; m < MT; ++m) o[nn][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // unused slots carry +inf so that their scores never trigger the max-raising path
-        mrun[nn] = rowbit[nn] ? -INFINITY : INFINITY;
+        mrun[nn] = rowbit(nn) ? -INFINITY : INFINITY;
         lrun[nn] = 0.f;
     }
     const float c2 = P.scale * LOG2E;
+    x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = Elt<T>::from_f(1.f);
 
     // ---- (3) block schedule = set bits of the union bitmap, ascending (wave-uniform scalars)
     int iw = 0;
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
 #pragma unroll
                 for (int s = 0; s < KS; ++s) sacc[u] = M::mma(kfr[u][s], qf[nn][s], sacc[u]);
             }
-            const bool on = (fullm & rowbit[nn]) != 0u;
+            const unsigned rbit = rowbit(nn);
+            const bool on = (fullm & rbit) != 0u;
             float x[16];
             unsigned vbits;  // bit 4u+j: key 16u + 4q + j of the block is selected by this slot's row
             float tmax;
@@ -318,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
                     for (int j = 0; j < 4; ++j) x[4 * u + j] = fmaf(sacc[u][j], c2, mneg);
             } else {
                 unsigned lo32 = on ? 0xffffffffu : 0u, hi32 = lo32;
-                if (partm & rowbit[nn]) {
-                    lo32 = kmask[2 * tokn[nn]];
-                    hi32 = kmask[2 * tokn[nn] + 1];
+                if (partm & rbit) {
+                    lo32 = kmask[2 * (nn * tpt + tsub)];
+                    hi32 = kmask[2 * (nn * tpt + tsub) + 1];
                 }
                 lo32 >>= 4 * q;
                 hi32 >>= 4 * q;
@@ -355,8 +362,13 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float pe = __builtin_amdgcn_exp2f(x[i]);
-                psum += pe;
+                if constexpr (!RS) psum += pe;
                 pf[i >> 3][i & 7] = Elt<T>::from_f(pe);
+            }
+            if constexpr (RS) {
+                f32x4 ls = M::mma(ones, pf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
+                ls = M::mma(ones, pf[1], ls);
+                psum = ls[0];
             }
             lrun[nn] += psum;
 #pragma unroll
@@ -371,10 +383,13 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     // ---- epilogue
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
-        float ltot = lrun[nn] + __shfl_xor(lrun[nn], 16, 64);
-        ltot += __shfl_xor(ltot, 32, 64);
-        if (!rowbit[nn]) continue;
-        const int64_t orow = (((int64_t)b * P.S + tw0 + tokn[nn]) * P.G + g) * h + head;
+        float ltot = lrun[nn];
+        if constexpr (!RS) {  // per-lane partial sums over the lane's 16 keys of every block -> column sum
+            ltot += __shfl_xor(ltot, 16, 64);
+            ltot += __shfl_xor(ltot, 32, 64);
+        }
+        if (!rowbit(nn)) continue;
+        const int64_t orow = (((int64_t)b * P.S + tw0 + nn * tpt + tsub) * P.G + g) * h + head;
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
         T *Or = (T *)P.O + orow * D;
 #pragma unroll
@@ -437,7 +452,8 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
         NSA_CHECK_ARG(c <= 16 && SP.W <= 64 && SP.W == P.n, "fused selection: S_sel <= 1024 and at most 64 ranges per row");
         cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
     }
-    void (*k)(SelAttnParams, SelectParams, int) = sel_attn_blocks_mfma_kernel<T, NT>;
+    void (*k)(SelAttnParams, SelectParams, int) =
+        tuning(TUNE_SEL_ROWSUM) ? sel_attn_blocks_mfma_kernel<T, NT, true> : sel_attn_blocks_mfma_kernel<T, NT, false>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_blocks_mfma");

@@ -544,11 +544,13 @@ static size_t decode_fused_lds(int h, int S_cmp, int S_sel) {
 
 // fused route available?  (bf16/f16 MFMA shapes, the row's logits fit in LDS)
 bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_sel, int64_t csb, int64_t csg, int64_t css, const void *Q,
-                                   const void *Kc) {
+                                   const void *Kc, int64_t rows) {
     if (tuning(TUNE_DECODE_UNFUSED)) return false;  // A/B switch for measurements and for the equivalence test
+    // one workgroup per row sweeps the row's whole K_cmp: with few rows and a long context the 3-kernel route (one wave per 64 compressed
+    // rows, spread over the chip) is faster (64k, B = 1: 73.6 vs 79.8 us per layer step); with >= 64 rows every CU has a row either way
+    const bool long_ok = S_cmp <= 2048 || rows >= 64;
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && (Dk == 64 || Dk == 128) && h <= 16 && S_cmp >= 1 && S_sel >= 1 &&
-           S_sel <= 64 * 32 && css % 8 == 0 && csb % 8 == 0 && csg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)Kc % 16 == 0) &&
-           S_cmp <= 2048 &&  // beyond ~32k context the wider 3-kernel route wins (measured: 64k 73.6 vs 79.8 us per layer step)
+           S_sel <= 64 * 32 && css % 8 == 0 && csb % 8 == 0 && csg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)Kc % 16 == 0) && long_ok &&
            decode_fused_lds(h, S_cmp, S_sel) <= 150 * 1024;
 }
 

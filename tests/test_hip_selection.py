@@ -214,7 +214,7 @@ def test_decode_scorer_vs_oracle(nv, orc, S_ctx, B, h, D, geom, dtype):
     assert norm(r.cpu().numpy()) == norm(r_ref)
 
 
-@pytest.mark.parametrize("S_ctx,B", [(65536, 1), (16384, 5), (200, 3), (70, 2)])
+@pytest.mark.parametrize("S_ctx,B", [(65536, 1), (65536, 32), (16384, 5), (200, 3), (70, 2)])
 def test_fused_decode_step(nv, orc, S_ctx, B):
     """nsa_sel_decode_step == the three separate calls, and == the oracle's decode chain (bf16, m7c shape)."""
     rng = np.random.default_rng([S_ctx, B])
@@ -301,7 +301,7 @@ def test_full_size_64k_selection_properties(nv):
     assert torch.equal(r, nv.select_topn_ranges_batched(p, m, n, S))
 
 
-@pytest.mark.parametrize("S_ctx,B", [(40, 1), (700, 3), (5000, 2), (16400, 1), (65536, 1)])
+@pytest.mark.parametrize("S_ctx,B", [(40, 1), (700, 3), (5000, 2), (16400, 1), (65536, 1), (65536, 32)])
 def test_fused_decode_scorer_equals_three_kernel_route(nv, S_ctx, B, tune):
     """decode: logits -> statistics -> Eq.9/10 -> top-n in one launch must give the ranges (bit-exact) and the output of the
     three-kernel route (tuning switch DECODE_UNFUSED = 1), which the other tests pin against the oracle / reference goldens"""

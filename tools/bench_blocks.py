@@ -14,16 +14,17 @@ import nsa_vibe_amd as nv  # noqa: E402
 
 dev = torch.device("cuda", 0)
 shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(4096, 8), (16384, 2), (65536, 1)]
-MODES = [("rows1", 1, 0), ("blk1", -1, 1), ("blk2", -1, 2), ("blk4", -1, 4)]
+MODES = [("rows1", 1, 0, 1), ("blk2", -1, 2, 1), ("blk4_vadd", -1, 4, 0), ("blk4", -1, 4, 1)]
 for S, B in shapes:
     meta, Q, Kc, K, V = bench.make_inputs(nv, B, S, dev, 1234)
     p = nv.selection_scores(Q, Kc, meta, 0.125, causal_skip=True, leave_skipped=True)
     res = {m[0]: [] for m in MODES}
     outs = {}
     for rnd in range(4):
-        for name, rows, blocks in MODES:
+        for name, rows, blocks, rowsum in MODES:
             nv._lib.set_tuning("SEL_ROWS", rows)
             nv._lib.set_tuning("SEL_BLOCKS", blocks)
+            nv._lib.set_tuning("SEL_ROWSUM", rowsum)
             fn = lambda: nv.select_and_attend(p, Q, K, V, meta, bench.N_SEL, mode="batched")  # noqa: E731
             res[name].append(bench.time_events(fn, 5, warm=1))
             if rnd == 0:
