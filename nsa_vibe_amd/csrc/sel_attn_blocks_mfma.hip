@@ -411,10 +411,12 @@ int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n,
     if (kss != 64 || vss != 64) return 0;  // the DMA steps through rows 128 B apart (rows of a [.., S, 64] cache are)
     const int mode = tuning(TUNE_SEL_BLOCKS);
     if (mode == 0) return 0;
-    // automatic choice (same-box A/B, profiles/r02/c_kernel_form_sweep.txt): while the rows of a wave share most of their blocks
+    // automatic choice (same-box A/B, profiles/r02/c_kernel_form_sweep*.txt): while the rows of a wave share most of their blocks
     // (S_kv up to ~8 x the n*l' tokens a row selects) the block form is 9-16 % faster than the query-tile pairs; beyond that every
-    // block serves one row, the second wave per SIMD that its 16 KiB tile costs matters more, and the pairs win by 8-10 %
-    if (mode < 0 && (int64_t)S_kv > (int64_t)512 * n) return 0;
+    // block serves one row, the two extra waves per SIMD of the pairs matter more and they win by 5 % -- until K/V outgrows the L2s
+    // (S_kv >= 48k at n = 16): the launch is then bound by L2-miss traffic and the block form moves 7 % less of it (the three
+    // forced blocks are fetched once per 8 rows instead of once per pair)
+    if (mode < 0 && (int64_t)S_kv > (int64_t)512 * n && (int64_t)S_kv < (int64_t)3072 * n) return 0;
     const int tpt = 16 / h;
     int nt = (mode == 1 || mode == 2 || mode == 4) ? mode : 4;
     while (nt > 1 && nt * tpt > 32) nt >>= 1;  // ownership masks are 32 bits wide

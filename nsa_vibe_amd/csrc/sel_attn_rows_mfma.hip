@@ -28,12 +28,20 @@ __device__ __forceinline__ unsigned bit_span(int lo, int hi) {  // bits lo..hi i
     return up & ~((1u << lo) - 1u);
 }
 
+// one v_max3_f32 (fmaxf makes hipcc canonicalise every MFMA-derived operand with a v_max x,x first)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ void lds_or(unsigned *p, unsigned v) {  // ds_or_b32: stays in the wave's in-order DS queue
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     __hip_atomic_fetch_or((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-template <typename T, int D, int NT>
+// RS: row sums of P on the matrix pipe (l += ones . P^T, one MFMA per tile instead of 8 v_add; see sel_attn_blocks_mfma.hip)
+template <typename T, int D, int NT, bool RS>
 __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     using M = MfmaT<T>;
     using G_ = Geo<D>;
@@ -220,6 +228,9 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
         lrun[nn] = 0.f;
     }
     const float c2 = P.scale * LOG2E;
+    x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = Elt<T>::from_f(1.f);
 
     // ---- (3) tile schedule = set bits of the union bitmap, ascending (wave-uniform scalars)
     int iw = 0;
@@ -336,9 +347,10 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float pe = __builtin_amdgcn_exp2f(x[nn][j]);
-                    psum += pe;
+                    if constexpr (!RS) psum += pe;
                     pf[j] = Elt<T>::from_f(pe);
                 }
+                if constexpr (RS) psum = M::mma(ones, pf, (f32x4){0.f, 0.f, 0.f, 0.f})[0];
                 lrun[nn] += psum;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) o[nn][m] = M::mma(va[m], pf, o[nn][m]);
@@ -374,15 +386,13 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
                 }
                 float xs[8];
                 float tmax = -INFINITY;
-                if (partm == 0u) {  // every slot is all-on or all-off: one predicate per lane
+                if (partm == 0u) {  // every slot is all-on or all-off: the softmax offset carries the mask (s*c2 - inf = -inf)
+                    const float mneg = on ? -mrun[nn] : -INFINITY;
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = on ? fmaf(sacc[u][j], c2, -mrun[nn]) : -INFINITY;
-                            xs[4 * u + j] = v;
-                            tmax = fmaxf(tmax, v);
-                        }
+                        for (int j = 0; j < 4; ++j) xs[4 * u + j] = fmaf(sacc[u][j], c2, mneg);
+                    tmax = max3f(max3f(xs[0], xs[1], xs[2]), max3f(xs[3], xs[4], xs[5]), max3f(xs[6], xs[7], xs[7]));
                 } else {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
@@ -420,9 +430,10 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float pe = __builtin_amdgcn_exp2f(xs[j]);
-                    psum += pe;
+                    if constexpr (!RS) psum += pe;
                     pf[j] = Elt<T>::from_f(pe);
                 }
+                if constexpr (RS) psum = M::mma(ones, pf, (f32x4){0.f, 0.f, 0.f, 0.f})[0];
                 lrun[nn] += psum;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) o[nn][m] = M::mma(va[m], pf, o[nn][m]);
@@ -434,8 +445,11 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
     // ---- epilogue
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
-        float ltot = lrun[nn] + __shfl_xor(lrun[nn], 16, 64);
-        ltot += __shfl_xor(ltot, 32, 64);
+        float ltot = lrun[nn];
+        if constexpr (!RS) {
+            ltot += __shfl_xor(ltot, 16, 64);
+            ltot += __shfl_xor(ltot, 32, 64);
+        }
         if (orow[nn] < 0) continue;
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
         T *Or = (T *)P.O + orow[nn] * D;
@@ -496,7 +510,8 @@ static int launch_rows_t(const SelAttnParams &P0, int tpw, hipStream_t st) {
         NSA_CHECK_ARG(c <= 16 && SP.W <= 64 && SP.W == P.n, "fused selection: S_sel <= 1024 and at most 64 ranges per row");
         cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
     }
-    void (*k)(SelAttnParams, SelectParams, int) = sel_attn_rows_mfma_kernel<T, D, NT>;
+    void (*k)(SelAttnParams, SelectParams, int) =
+        tuning(TUNE_SEL_ROWSUM) ? sel_attn_rows_mfma_kernel<T, D, NT, true> : sel_attn_rows_mfma_kernel<T, D, NT, false>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_rows_mfma");

@@ -14,7 +14,7 @@ import nsa_vibe_amd as nv  # noqa: E402
 
 dev = torch.device("cuda", 0)
 shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(4096, 8), (16384, 2), (65536, 1)]
-MODES = [("rows1", 1, 0, 1), ("blk2", -1, 2, 1), ("blk4_vadd", -1, 4, 0), ("blk4", -1, 4, 1)]
+MODES = [("rows1_vadd", 1, 0, 0), ("rows1", 1, 0, 1), ("blk2", -1, 2, 1), ("blk4", -1, 4, 1)]
 for S, B in shapes:
     meta, Q, Kc, K, V = bench.make_inputs(nv, B, S, dev, 1234)
     p = nv.selection_scores(Q, Kc, meta, 0.125, causal_skip=True, leave_skipped=True)
@@ -29,10 +29,10 @@ for S, B in shapes:
             res[name].append(bench.time_events(fn, 5, warm=1))
             if rnd == 0:
                 outs[name] = fn()
-    ref = outs["rows1"]
+    ref = outs["rows1_vadd"]
     line = f"S={S} B={B}: " + "  ".join(f"{k} {np.median(v) * 1e3:8.1f} us (min {min(v) * 1e3:.1f})" for k, v in res.items())
     errs = {k: (bool(torch.equal(o[0], ref[0])), float((o[1].float() - ref[1].float()).abs().max())) for k, o in outs.items()}
     print(line)
-    print("   ranges equal / max|dO| vs rows1:", errs, flush=True)
+    print("   ranges equal / max|dO| vs rows1_vadd:", errs, flush=True)
     del Q, Kc, K, V, p, outs
     torch.cuda.empty_cache()
