@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STOP"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, 0, -1, -1, 1, 0};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "DECODE_STOP"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -612,15 +612,16 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
     const float sc = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
     const bool wg_attn = sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, kss, vss, Q, K, V) && S_kv >= 1 &&
                          (int64_t)S_kv * 128 < ((int64_t)1 << 31);
+    const int stencil = (l == 2 * d && l_sel == 4 * d) ? 1 : 0;  // Eq.9 in closed form (the fused kernel then reads no CSC arrays)
     if (decode_score_select_supported(dtype, h, Dk, S_cmp, S_sel, kcb, kcg, kcs, Q, K_cmp, (int64_t)B * G)) {
         if (wg_attn) {  // scores -> statistics -> Eq.9/10 -> sequential top-n -> selection attention: ONE launch, O is final
             if (ns_used) *ns_used = 1;
             return launch_decode_score_select_attend(Q, K_cmp, K, V, O, B, G, h, Dk, S_cmp, S_kv, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg, vss, csc_ptr,
-                                                     csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype, sc, ranges_out, (hipStream_t)stream);
+                                                     csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype, sc, ranges_out, (hipStream_t)stream, stencil);
         }
         // scores -> statistics -> Eq.9/10 -> sequential top-n in one launch (bit-identical to the route below)
         rc = launch_decode_score_select(Q, K_cmp, B, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token,
-                                        dtype, sc, ranges_out, (hipStream_t)stream, nullptr);
+                                        dtype, sc, ranges_out, (hipStream_t)stream, nullptr, stencil);
         if (rc) return rc;
     } else {
         rc = nsa_sel_scores(Q, K_cmp, p_grp, B, 1, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l, d, l_sel, 1,

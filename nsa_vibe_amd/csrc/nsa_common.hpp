@@ -39,10 +39,11 @@ enum Tune {
     TUNE_ATTN_MAP,          // NSA_HIP_ATTN_MAP: one-row kernel workgroup mapping, -1 auto
     TUNE_ATTN_STAGE,        // NSA_HIP_ATTN_STAGE: 0 register staging, 1 LDS-DMA (default)
     TUNE_BAND_STAGE,        // NSA_HIP_BAND_STAGE: same for the band kernel
-    TUNE_DECODE_UNFUSED,    // NSA_HIP_DECODE_UNFUSED: 1 = three-kernel decode scorer route
+    TUNE_DECODE_UNFUSED,    // NSA_HIP_DECODE_UNFUSED: 1 = three-kernel decode scorer route, 0 = fused whenever it fits, -1 auto
     TUNE_SEL_BLOCKS,        // NSA_HIP_SEL_BLOCKS: 64-key block form of the selection forward, -1 auto, 0 off, N = row pairs per wave
     TUNE_DECODE_WG,         // NSA_HIP_DECODE_WG: decode attention as one workgroup per row (+ fused into the decode scorer), -1 auto, 0 off
     TUNE_SEL_ROWSUM,        // NSA_HIP_SEL_ROWSUM: block-form forward, row sums of P by MFMA (1) or by v_add (0)
+    TUNE_DECODE_STENCIL,    // NSA_HIP_DECODE_STENCIL: fused decode kernel, 1 = closed-form Eq.9 taps for l = 2d, l' = 4d; 0 = always the CSC
     TUNE_DECODE_STOP,       // NSA_HIP_DECODE_STOP: measurement aid, the fused decode kernel returns after phase N (1 logits, 2 scores, 3 top-n); 0 = run all
     TUNE_COUNT
 };
@@ -86,6 +87,13 @@ struct Elt<_Float16> {
 // ---- wave helpers ----------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// a kernel argument (or any wave-uniform value) materialised in scalar registers HERE: its scalar load is issued at this point of the
+// program instead of right before its first use
+template <typename V>
+__device__ __forceinline__ void pin_sgpr(V &x) {
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8, "pin_sgpr: 32- or 64-bit values");
+    asm volatile("" : "+s"(x));
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -25,10 +25,12 @@ bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_se
 struct DecAttnArgs;  // sel_attn_decode.hpp: non-null = the row's selection attention runs in the same launch
 int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg, int64_t css,
                                const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,
-                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st, const DecAttnArgs *attend);
+                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st, const DecAttnArgs *attend,
+                               int stencil);
 int launch_decode_score_select_attend(const void *Q, const void *Kc, const void *K, const void *V, void *O, int B, int G, int h, int Dk, int S_cmp,
                                       int S_kv, int64_t csb, int64_t csg, int64_t css, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
                                       int64_t vsg, int64_t vss, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
-                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st);
+                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st,
+                                      int stencil);
 
 }  // namespace nsa

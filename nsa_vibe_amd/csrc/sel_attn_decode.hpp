@@ -15,6 +15,12 @@
 #include "attn_mfma_tiles.hpp"
 
 namespace nsa {
+#ifdef NSA_DEC_TS
+static __device__ long long g_dec_ts[64];
+#define DEC_TS(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_dec_ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DEC_TS(i)
+#endif
 
 struct DecAttnArgs {
     const void *Q;  // [R,h,64]
@@ -34,8 +40,10 @@ constexpr int DEC_ATT_LDS = DEC_ATT_WAVES * DEC_ATT_TILE + DEC_ATT_TAIL;
 // lds: DEC_ATT_LDS bytes, 16-byte aligned; lanes i < n of wave 0 pass range i in (rs, re) (unclamped); every thread of the
 // 1024-thread workgroup must call (two workgroup barriers inside).  SORTED: the ranges are ascending and disjoint with the live ones
 // first (what select_topn_row_regs emits): the sort / union pass is skipped, only the clamp to [0, S_kv] remains.
+// qf_in: the row's Q^T fragments if the caller holds them already (lane (rho, q): Q[head min(rho, h-1)][32 s + 8 q ..], s = 0, 1).
 template <typename T, bool SORTED = false>
-__device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t row, int rs, int re, unsigned char *lds) {
+__device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t row, int rs, int re, unsigned char *lds,
+                                                  const typename MfmaT<T>::x8 *qf_in = nullptr) {
     using M = MfmaT<T>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
@@ -49,14 +57,12 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
     int *seg = (int *)(lds + DEC_ATT_WAVES * DEC_ATT_TILE);
     unsigned char *vl = lds + wave * DEC_ATT_TILE;
 
-    // Q^T fragments (B operand): column = head
+    // Q^T fragments (B operand): column = head (columns >= h repeat the last head: their results are never stored)
     x8 qf[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u32x4 raw = {0u, 0u, 0u, 0u};
-        if (rho < h) raw = *(const u32x4 *)((const T *)A.Q + (row * h + rho) * 64 + 32 * s + 8 * q);
-        qf[s] = __builtin_bit_cast(x8, raw);
-    }
+    for (int s = 0; s < 2; ++s)
+        qf[s] = qf_in ? qf_in[s] : __builtin_bit_cast(x8, *(const u32x4 *)((const T *)A.Q + (row * h + min(rho, h - 1)) * 64 + 32 * s + 8 * q));
+    DEC_TS(10);
     int nseg, sstart = 0, slen = 0;  // chunk table in registers: lane i holds segment i (start, length)
     if constexpr (SORTED) {
         if (wave == 0 && lane < A.n) {
@@ -95,6 +101,7 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
     }
     const int cb = inc - nck;
     const int NC = uniform(__shfl(inc, 63, 64));
+    DEC_TS(11);
 
     const unsigned char *Kb = (const unsigned char *)((const T *)A.K + b * A.ksb + (int64_t)g * A.ksg);
     const unsigned char *Vb = (const unsigned char *)((const T *)A.V + b * A.vsb + (int64_t)g * A.vsg);
@@ -151,6 +158,7 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
 #pragma unroll
             for (int s = 0; s < 2; ++s) sacc[u] = M::mma(kfr[u][s], qf[s], sacc[u]);
         }
+        DEC_TS(12);
         float x[16];
         float vmax = -INFINITY;
 #pragma unroll
@@ -175,8 +183,10 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
             pf[i >> 3][i & 7] = Elt<T>::from_f(pe);
         }
         lrun = lrun * alpha + psum;
+        DEC_TS(13);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the V pieces have landed (LDS-DMA completion is a vmcnt event)
         __builtin_amdgcn_sched_barrier(0);
+        DEC_TS(14);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             o[m] *= alpha;
@@ -195,6 +205,7 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // transposing reads done before the next chunk's DMA overwrites the tile
         __builtin_amdgcn_sched_barrier(0);
     }
+    DEC_TS(15);
     // ---- partial record of this wave over its own V tile: m[16] | l[16] | o[16 slots][64]
     float ltot = lrun + __shfl_xor(lrun, 16, 64);
     ltot += __shfl_xor(ltot, 32, 64);
@@ -206,6 +217,7 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
 #pragma unroll
     for (int m = 0; m < 4; ++m) *(f32x4 *)(po + rho * 64 + 16 * m + 4 * q) = o[m];
     __syncthreads();
+    DEC_TS(16);
     // ---- merge: thread (head, d) walks the 16 partial records in wave order (fixed order: bitwise reproducible)
     const int tid = threadIdx.x;
     if (tid < h * 64) {
@@ -225,6 +237,7 @@ __device__ __forceinline__ void decode_attend_row(const DecAttnArgs &A, int64_t 
         }
         ((T *)A.O)[(row * h + hh) * 64 + d] = Elt<T>::from_f(l > 0.f ? acc / l : 0.f);
     }
+    DEC_TS(17);
 }
 
 }  // namespace nsa

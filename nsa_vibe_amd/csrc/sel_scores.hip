@@ -12,8 +12,8 @@
 #include <stdlib.h>
 
 #include "nsa_common.hpp"
-#include "sel_select_row.hpp"
 #include "sel_attn_decode.hpp"
+#include "sel_select_row.hpp"
 #include "nsa_internal.hpp"
 
 namespace nsa {
@@ -153,6 +153,7 @@ struct DecodeParams {
     int S, G, h, Dk, S_cmp, S_sel;
     int64_t csb, csg, css;
     float c2;
+    int stencil;  // fused decode kernel: l = 2d and l' = 4d, Eq.9 is the closed-form 5-tap stencil (no CSC loads)
 };
 
 constexpr int DEC_HMAX = 16;
@@ -384,7 +385,7 @@ template <typename T, int KSTEPS, bool ATTEND>
 __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams P, SelectParams SP, int cand, int t_token, DecAttnArgs AT, int stop) {
     typedef typename std::conditional<std::is_same<T, __bf16>::value, bf16x8, f16x8>::type x8;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6), rho = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6)), rho = lane & 15, q = lane >> 4;
     constexpr int NW = 16;
     const int64_t row = blockIdx.x;
     const int nchunk = dec_nchunk(P.S_cmp);
@@ -392,30 +393,57 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
     float *part = xs + (size_t)P.h * P.S_cmp;          // [h][nchunk][2]
     float *mlog_s = part + (size_t)P.h * nchunk * 2;   // [64]
     float *pg = mlog_s + 64;                           // [S_sel]
+    int *scr = (int *)(pg + P.S_sel);                  // [128] run extraction scratch of the selector
     const int g = (int)(row % P.G);
     const int b = (int)(row / ((int64_t)P.G * P.S));
     constexpr int Dk = 32 * KSTEPS;
-    // ---- phase 1: logits of 64 compressed rows per wave and step (MFMA rows), heads = columns
-    {
-        x8 qf[KSTEPS];
+    DEC_TS(0);
+    // ---- phase 0 (generic block geometry only): the Eq.9 taps of this thread's selection block go out first (csc_ptr -> rows / weights
+    // are two dependent global round trips, 3 us when they start in phase 2b; here they fly behind the K_cmp loads of phase 1).  The default
+    // geometry (l = 2d, l' = 4d) needs no table: block j takes rows 4j-1 .. 4j+3 with weights 1/2, 1, 1, 1, 1/2 -- the
+    // CSC of a decode cache whose meta is older than its K_cmp lacks the newest rows, but those only reach the current and the previous
+    // block, both forced: the ranges are the same (p_grp stays inside the kernel).
+    const int j_pre = wave * 64 + lane;  // the block of this thread in the first round of phase 2b
+    int k0_pre = 0, k1_pre = 0, rr_pre[8];
+    float vv_pre[8];
+    if (!P.stencil) {
+        const int jj = min(j_pre, P.S_sel - 1);  // unconditional loads (clamped): see taps_pre
+        k0_pre = P.csc_ptr[jj];
+        k1_pre = P.csc_ptr[jj + 1];
+    }
+    auto taps_pre = [&]() {  // second hop: issued behind the first K_cmp loads, so waiting for csc_ptr does not hold those back.  The
+                             // loads are unconditional (index clamped into the column, or to entry 0: S_cmp >= 1 means nnz >= 1) and
+                             // their values are not looked at before phase 2b
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            u32x4 raw = {0u, 0u, 0u, 0u};
-            if (rho < P.h) raw = *(const u32x4 *)((const T *)P.Q + (row * P.h + rho) * (int64_t)Dk + 32 * s + 8 * q);
-            qf[s] = __builtin_bit_cast(x8, raw);
+        for (int t = 0; t < 8; ++t) {
+            const int k = max(min(k0_pre + t, k1_pre - 1), 0);
+            rr_pre[t] = P.csc_rows[k];
+            vv_pre[t] = P.csc_vals[k];
         }
+    };
+    // ---- phase 1: logits of 64 compressed rows per wave and step (MFMA rows), heads = columns
+    x8 qf[KSTEPS];  // columns >= h repeat the last head: their results are never stored (kept for the attention phase)
+    {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) qf[s] = *(const x8 *)((const T *)P.Q + (row * P.h + min(rho, P.h - 1)) * (int64_t)Dk + 32 * s + 8 * q);
         const T *kb = (const T *)P.Kc + (int64_t)b * P.csb + (int64_t)g * P.csg;
-        for (int chunk = wave; chunk < nchunk; chunk += NW) {
-            f32x4 acc[4];
+        auto load_chunk = [&](int chunk, x8 (&a)[4][KSTEPS]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = min(chunk * 64 + 16 * u + rho, P.S_cmp - 1);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) a[u][s] = *(const x8 *)(kb + (int64_t)c * P.css + 32 * s + 8 * q);
+            }
+        };
+        auto do_chunk = [&](int chunk, const x8 (&a)[4][KSTEPS]) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) {
-                    const x8 a = *(const x8 *)(kb + (int64_t)c * P.css + 32 * s + 8 * q);
-                    if constexpr (std::is_same<T, __bf16>::value) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[s], acc[u], 0, 0, 0);
-                    else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[s], acc[u], 0, 0, 0);
+                    if constexpr (std::is_same<T, __bf16>::value) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][s], qf[s], acc[u], 0, 0, 0);
+                    else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][s], qf[s], acc[u], 0, 0, 0);
                 }
             }
             float m = -INFINITY;
@@ -442,15 +470,28 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
                     if (chunk * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(x[4 * u + j] - m);
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
-            if (q == 0 && rho < P.h) {
+            if (q == 0 && rho < P.h && chunk < nchunk) {
                 float *pr = part + ((size_t)rho * nchunk + chunk) * 2;
                 pr[0] = m;
                 pr[1] = l;
             }
+        };
+        // first chunk: loads unconditional and in straight-line code (a chunk past the end re-reads the last row and stores nothing),
+        // the taps' second hop right behind them -- exact wait counts: the MFMAs wait for K_cmp only, not for the taps
+        x8 a[4][KSTEPS];
+        load_chunk(wave, a);
+        __builtin_amdgcn_sched_barrier(0);  // the K_cmp loads go out before anything waits for csc_ptr
+        if (!P.stencil) taps_pre();
+        do_chunk(wave, a);
+        for (int chunk = wave + NW; chunk < nchunk; chunk += NW) {
+            load_chunk(chunk, a);
+            do_chunk(chunk, a);
         }
     }
     if (stop == 1) return;  // measurement aid (TUNE_DECODE_STOP): every thread leaves together
+    DEC_TS(1);
     __syncthreads();
+    DEC_TS(2);
     // ---- phase 2a: softmax statistics per head (one wave per head)
     for (int hh = wave; hh < P.h; hh += NW) {
         const float *pr = part + (size_t)hh * nchunk * 2;
@@ -471,29 +512,75 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
         if (lane == 0) mlog_s[hh] = m + __builtin_amdgcn_logf(l);
     }
     __syncthreads();
+    DEC_TS(3);
     // ---- phase 2b: Eq.9 taps + Eq.10 head sum, lane = selection block
+    const int nslab = (P.S_sel + 63) >> 6;
+    if (P.stencil && 2 * nslab <= NW) {
+        // fewer 64-block slabs than waves (16k context: 4): a (slab, head) pair per wave instead of a slab with all its heads -- a head is
+        // one dependent chain (LDS round trip, 5 exp, 5 adds) and a SIMD with one active wave runs it at latency; the head sums are then
+        // added in ascending head order as before (bit-identical)
+        float *acch = (float *)(scr + 128);  // [h][S_sel]
+        for (int item = wave; item < nslab * P.h; item += NW) {
+            const int hh = item / nslab, j = (item - hh * nslab) * 64 + lane;
+            if (j >= P.S_sel) continue;
+            const float *x = xs + (size_t)hh * P.S_cmp;
+            const float ml = mlog_s[hh];
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int r = 4 * j - 1 + t;
+                const bool ok = r >= 0 && r < P.S_cmp;
+                const float nxt = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[ok ? r : 0] - ml), (t == 0 || t == 4) ? 0.5f : 1.0f));
+                acc = ok ? nxt : acc;
+            }
+            acch[(size_t)hh * P.S_sel + j] = acc;
+        }
+        __syncthreads();
+        for (int jb = wave; jb < nslab; jb += NW) {
+            const int j = jb * 64 + lane;
+            if (j >= P.S_sel) continue;
+            float grp = 0.f;
+            for (int hh = 0; hh < P.h; ++hh) grp = __fadd_rn(grp, acch[(size_t)hh * P.S_sel + j]);
+            pg[j] = grp;
+        }
+    } else
     for (int jb = wave; jb * 64 < P.S_sel; jb += NW) {
         const int j = jb * 64 + lane;
         if (j >= P.S_sel) continue;
-        const int k0 = P.csc_ptr[j], k1 = P.csc_ptr[j + 1];
+        const bool pre = jb == wave;  // the taps fetched in phase 0
+        const int k0 = P.stencil ? 0 : pre ? k0_pre : P.csc_ptr[j], k1 = P.stencil ? 5 : pre ? k1_pre : P.csc_ptr[j + 1];
         float grp = 0.f;
-        if (k1 - k0 <= 8) {  // taps once (global), logits from LDS
+        if (k1 - k0 <= 8) {  // taps once, logits from LDS
             int rr[8];
             float vv[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const bool ok = k0 + t < k1;
-                const int r = ok ? P.csc_rows[k0 + t] : P.S_cmp;
-                rr[t] = r < P.S_cmp ? r : -1;
-                vv[t] = ok ? P.csc_vals[k0 + t] : 0.f;
+                int r = P.S_cmp;
+                float v = 0.f;
+                if (P.stencil) {
+                    r = ok ? 4 * j - 1 + t : P.S_cmp;
+                    v = (t == 0 || t == 4) ? 0.5f : 1.0f;
+                } else if (pre) {
+                    r = ok ? rr_pre[t] : P.S_cmp;
+                    v = ok ? vv_pre[t] : 0.f;
+                } else if (ok) {
+                    r = P.csc_rows[k0 + t];
+                    v = P.csc_vals[k0 + t];
+                }
+                rr[t] = (r >= 0 && r < P.S_cmp) ? r : -1;
+                vv[t] = v;
             }
             for (int hh = 0; hh < P.h; ++hh) {
                 const float *x = xs + (size_t)hh * P.S_cmp;
                 const float ml = mlog_s[hh];
                 float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    if (rr[t] >= 0) acc = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[rr[t]] - ml), vv[t]));
+                for (int t = 0; t < 8; ++t) {  // branch-free: the 8 LDS reads of a head are in flight together (a branch per tap made each
+                                               // read its own round trip: 48 of them, 2.5 us); a missing tap leaves acc untouched
+                    const float nxt = __fadd_rn(acc, __fmul_rn(__builtin_amdgcn_exp2f(x[max(rr[t], 0)] - ml), vv[t]));
+                    acc = rr[t] >= 0 ? nxt : acc;
+                }
                 grp = __fadd_rn(grp, acc);
             }
         } else {
@@ -511,19 +598,22 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
         pg[j] = grp;
     }
     if (stop == 2) return;
+    DEC_TS(4);
     __syncthreads();
+    DEC_TS(5);
     // ---- phase 3: top-n + forced blocks + merge (one wave)
     int rs = 0, re = 0;
     if (wave == 0) {
         int32_t *out = SP.out + row * (int64_t)SP.W * 2;
         switch (cand) {
-            case 1: select_topn_row_regs<1>(SP, pg, t_token, rs, re); break;
-            case 2: select_topn_row_regs<2>(SP, pg, t_token, rs, re); break;
-            case 4: select_topn_row_regs<4>(SP, pg, t_token, rs, re); break;
-            case 8: select_topn_row_regs<8>(SP, pg, t_token, rs, re); break;
-            case 16: select_topn_row_regs<16>(SP, pg, t_token, rs, re); break;
-            default: select_topn_row_regs<32>(SP, pg, t_token, rs, re); break;
+            case 1: select_topn_row_regs<1>(SP, pg, t_token, rs, re, scr); break;
+            case 2: select_topn_row_regs<2>(SP, pg, t_token, rs, re, scr); break;
+            case 4: select_topn_row_regs<4>(SP, pg, t_token, rs, re, scr); break;
+            case 8: select_topn_row_regs<8>(SP, pg, t_token, rs, re, scr); break;
+            case 16: select_topn_row_regs<16>(SP, pg, t_token, rs, re, scr); break;
+            default: select_topn_row_regs<32>(SP, pg, t_token, rs, re, scr); break;
         }
+        DEC_TS(6);
         if (lane < SP.W) {
             out[2 * lane] = rs;
             out[2 * lane + 1] = re;
@@ -534,21 +624,24 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
     if constexpr (ATTEND) {
         if (stop == 3) return;
         __syncthreads();
-        if constexpr (KSTEPS == 2) decode_attend_row<T, true>(AT, row, rs, re, (unsigned char *)dsm);
+        DEC_TS(7);
+        if constexpr (KSTEPS == 2) decode_attend_row<T, true>(AT, row, rs, re, (unsigned char *)dsm, qf);
     }
 }
 
 static size_t decode_fused_lds(int h, int S_cmp, int S_sel) {
-    return sizeof(float) * ((size_t)h * S_cmp + (size_t)h * dec_nchunk(S_cmp) * 2 + 64 + (size_t)S_sel);
+    const size_t split = 2 * ((S_sel + 63) / 64) <= 16 ? (size_t)h * S_sel : 0;  // per-head block sums of the head-split phase 2b
+    return sizeof(float) * ((size_t)h * S_cmp + (size_t)h * dec_nchunk(S_cmp) * 2 + 64 + (size_t)S_sel + 128 + split);
 }
 
 // fused route available?  (bf16/f16 MFMA shapes, the row's logits fit in LDS)
 bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_sel, int64_t csb, int64_t csg, int64_t css, const void *Q,
                                    const void *Kc, int64_t rows) {
-    if (tuning(TUNE_DECODE_UNFUSED)) return false;  // A/B switch for measurements and for the equivalence test
+    const int mode = tuning(TUNE_DECODE_UNFUSED);  // A/B switch for measurements and for the equivalence test: -1 auto, 0 fused, 1 unfused
+    if (mode > 0) return false;
     // one workgroup per row sweeps the row's whole K_cmp: with few rows and a long context the 3-kernel route (one wave per 64 compressed
     // rows, spread over the chip) is faster (64k, B = 1: 73.6 vs 79.8 us per layer step); with >= 64 rows every CU has a row either way
-    const bool long_ok = S_cmp <= 2048 || rows >= 64;
+    const bool long_ok = mode == 0 || S_cmp <= 2048 || rows >= 64;
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && (Dk == 64 || Dk == 128) && h <= 16 && S_cmp >= 1 && S_sel >= 1 &&
            S_sel <= 64 * 32 && css % 8 == 0 && csb % 8 == 0 && csg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)Kc % 16 == 0) && long_ok &&
            decode_fused_lds(h, S_cmp, S_sel) <= 150 * 1024;
@@ -556,10 +649,12 @@ bool decode_score_select_supported(int dtype, int h, int Dk, int S_cmp, int S_se
 
 int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg, int64_t css,
                                const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,
-                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st, const DecAttnArgs *attend) {
+                               int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st, const DecAttnArgs *attend,
+                               int stencil) {
     const int64_t R = (int64_t)B * G;
     NSA_CHECK_ARG(R <= 65535 * 32, "decode scorer: too many rows");
-    DecodeParams P{Q, Kc, nullptr, nullptr, nullptr, csc_ptr, csc_rows, csc_vals, R, 1, G, h, Dk, S_cmp, S_sel, csb, csg, css, scale * LOG2E};
+    DecodeParams P{Q, Kc, nullptr, nullptr, nullptr, csc_ptr, csc_rows, csc_vals, R, 1, G, h, Dk, S_cmp, S_sel, csb, csg, css, scale * LOG2E,
+                   stencil && tuning(TUNE_DECODE_STENCIL) ? 1 : 0};
     SelectParams SP{};
     if (int rc = select_params_sequential(&SP, S_sel, l_sel, n_top, 1, 2, n_top)) return rc;
     SP.out = ranges_out;
@@ -600,10 +695,11 @@ int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int 
 int launch_decode_score_select_attend(const void *Q, const void *Kc, const void *K, const void *V, void *O, int B, int G, int h, int Dk, int S_cmp,
                                       int S_kv, int64_t csb, int64_t csg, int64_t css, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
                                       int64_t vsg, int64_t vss, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
-                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st) {
+                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st,
+                                      int stencil) {
     const DecAttnArgs AT{Q, K, V, O, G, h, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, scale * LOG2E};
     return launch_decode_score_select(Q, Kc, B, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype,
-                                      scale, ranges_out, st, &AT);
+                                      scale, ranges_out, st, &AT, stencil);
 }
 
 size_t decode_scores_workspace(int64_t R, int h, int S_cmp) {
@@ -686,3 +782,9 @@ int launch_sel_scores(const void *Q, const void *Kc, float *p_grp, int B, int S,
 }
 
 }  // namespace nsa
+
+#ifdef NSA_DEC_TS
+extern "C" __attribute__((visibility("default"))) int nsa_debug_read_ts(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsa::g_dec_ts), sizeof(long long) * 64);
+}
+#endif

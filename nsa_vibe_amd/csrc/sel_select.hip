@@ -21,10 +21,11 @@ namespace nsa {
 
 template <int CAND>
 __global__ __launch_bounds__(256) void select_topn_kernel(SelectParams P) {
+    __shared__ int scr[4][128];  // run extraction scratch, one slice per wave
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= P.R) return;
     const int t = P.t_rows ? P.t_rows[row] : P.t0 + (int)((row / P.G) % P.S);
-    select_topn_row<CAND>(P, P.p_grp + row * (int64_t)P.S_sel, t, P.out + row * (int64_t)P.W * 2);
+    select_topn_row<CAND>(P, P.p_grp + row * (int64_t)P.S_sel, t, P.out + row * (int64_t)P.W * 2, scr[threadIdx.x >> 6]);
 }
 
 // ---- v2 converter alone: one thread per row -------------------------------------------------
@@ -105,6 +106,7 @@ int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, i
                   "select (sequential): bad sizes");
     P->S_sel = S_sel; P->l_sel = l_sel; P->n_top = n_top; P->force_init = force_init ? 1 : 0; P->force_local = force_local;
     P->mode = NSA_SEL_SEQUENTIAL; P->W = W;
+    P->l_sel_shift = (l_sel & (l_sel - 1)) == 0 ? __builtin_ctz((unsigned)l_sel) : -1;
     const int nf_all = P->force_init + force_local;
     const int k_rest = n_top - nf_all > 0 ? n_top - nf_all : 0;
     P->k_actual = k_rest < S_sel ? k_rest : S_sel;
@@ -118,6 +120,7 @@ int select_params_fill(SelectParams *Pp, int S_sel, int l_sel, int n_top, int fo
     SelectParams &P = *Pp;
     NSA_CHECK_ARG(S_sel >= 1 && S_sel <= 64 * 64 && l_sel >= 1 && n_top >= 0 && force_local >= 0 && force_local <= 30, "select: bad sizes");
     P.S_sel = S_sel; P.l_sel = l_sel; P.n_top = n_top; P.force_init = force_init ? 1 : 0; P.force_local = force_local; P.mode = mode; P.W = W;
+    P.l_sel_shift = (l_sel & (l_sel - 1)) == 0 ? __builtin_ctz((unsigned)l_sel) : -1;
     const int nf_all = P.force_init + force_local;
     if (mode == NSA_SEL_SEQUENTIAL) {
         NSA_CHECK_ARG(W == n_top, "select (sequential): out_width must be n_top");

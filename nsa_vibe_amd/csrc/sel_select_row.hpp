@@ -2,6 +2,9 @@
 #pragma once
 #include "nsa_common.hpp"
 
+#ifndef DEC_TS
+#define DEC_TS(i)
+#endif
 namespace nsa {
 
 struct SelectParams {
@@ -14,15 +17,21 @@ struct SelectParams {
     int n_forced;      // forced entries used (sequential: all; batched: kept columns, maybe truncated)
     unsigned keepmask; // batched: bit i = sorted forced column i is kept
     int all_valid;     // batched with n_top >= S_sel: select every valid block
+    int l_sel_shift;   // log2(l_sel) when l_sel is a power of two, else -1 (the block of a token without an integer division)
 };
 
 // one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS).  Lane i < min(W, 64) returns
 // range i in (my_s, my_e); ranges beyond the emitted runs are [0, 0).
+// scr: 128 ints of LDS private to the wave, or null.  With it the runs of the selected bitmap are extracted by all lanes at once (a lane
+// that starts / ends a run knows the run's index from the bits below it and drops the token bound into slot [index]); without it one
+// scalar loop walks the runs (about 30 dependent scalar instructions per run: 1.5 us of a decode step).
 template <int CAND>
-__device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, const float *p, const int t, int &my_s, int &my_e) {
+__device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, const float *p, const int t, int &my_s, int &my_e,
+                                                     int *scr = nullptr) {
     const int lane = lane_id();
     const int l_sel = P.l_sel, S_sel = P.S_sel;
-    const int nvalid_blocks = min(S_sel, (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
+    const int sh = P.l_sel_shift;
+    const int nvalid_blocks = min(S_sel, sh >= 0 ? (t + 1) >> sh : (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
 
     float key[CAND];
     unsigned long long selbits = 0ull;  // bit c = block lane + 64 c selected
@@ -35,31 +44,42 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         if (P.all_valid && j < nvalid_blocks) selbits |= 1ull << c;
     }
 
+    DEC_TS(20);
     if (!P.all_valid) {
         // ---- forced blocks
-        const int cblk = max(t / l_sel, 0);
+        const int cblk = max(sh >= 0 ? t >> sh : t / l_sel, 0);
         const int nf_all = (P.force_init ? 1 : 0) + P.force_local;
-        int used = 0;
-        for (int i = 0; i < nf_all; ++i) {
-            // sorted forced list: [0 (init)] then max(cblk - a, 0) with a descending to 0
-            int f;
-            if (P.force_init && i == 0) f = 0;
-            else f = max(cblk - (nf_all - 1 - i), 0);
-            if (P.mode == NSA_SEL_BATCHED) {
+        if (P.mode == NSA_SEL_SEQUENTIAL) {
+            // every entry of the forced list [0 (init)] + [max(cblk - a, 0) : a = force_local-1 .. 0] is taken, valid or not: block j is
+            // forced iff it is the initial block or lies in (cblk - force_local, cblk] (the clamp to 0 is the case force_local > cblk)
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                const int j = lane + 64 * c;
+                const bool f = ((P.force_init && j == 0) || (j <= cblk && j > cblk - P.force_local)) && j < S_sel;
+                key[c] = f ? -INFINITY : key[c];  // excluded from top-k
+                selbits |= f ? 1ull << c : 0ull;
+            }
+        } else {
+            int used = 0;
+            for (int i = 0; i < nf_all; ++i) {
+                // sorted forced list: [0 (init)] then max(cblk - a, 0) with a descending to 0
+                int f;
+                if (P.force_init && i == 0) f = 0;
+                else f = max(cblk - (nf_all - 1 - i), 0);
                 if (!((P.keepmask >> i) & 1u)) continue;
                 if (used >= P.n_forced) break;
-            }
-            ++used;
-            if (f >= S_sel) continue;
-            const bool valid = f < nvalid_blocks;
-            if ((f & 63) == lane) {
-                const int c = f >> 6;
+                ++used;
+                if (f >= S_sel) continue;
+                const bool valid = f < nvalid_blocks;
+                if ((f & 63) == lane) {
+                    const int c = f >> 6;
 #pragma unroll
-                for (int cc = 0; cc < CAND; ++cc)
-                    if (cc == c) {
-                        key[cc] = -INFINITY;                                              // excluded from top-k
-                        if (P.mode == NSA_SEL_SEQUENTIAL || valid) selbits |= 1ull << cc;   // batched drops invalid picks
-                    }
+                    for (int cc = 0; cc < CAND; ++cc)
+                        if (cc == c) {
+                            key[cc] = -INFINITY;                 // excluded from top-k
+                            if (valid) selbits |= 1ull << cc;  // batched drops invalid picks
+                        }
+                }
             }
         }
         // ---- top-k picks: threshold (radix) select on an order-preserving integer image of the key.
@@ -70,6 +90,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         // walks the sorted slots until the count reaches k or a slot has no key >= cand -- one or two ballots instead of CAND
         // (k = 13 of 1024 at S = 64k: slot 0, the 64 lane maxima, settles most rounds).  The picks are then made on the
         // original keys, slot by slot in ascending index order, skipping slots without a key >= T.
+        DEC_TS(21);
         unsigned u[CAND];
 #pragma unroll
         for (int c = 0; c < CAND; ++c) {
@@ -96,6 +117,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                                 w[ii + jj + kk] = min(a, b);
                             }
         }
+        DEC_TS(22);
         // counts are capped just above k: the search needs "at least k", and "exactly k" ends it early
         auto count_ge = [&](unsigned cand, int cap) -> int {
             int cnt = 0;
@@ -112,6 +134,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         if (k_eff > 0) {
             // MSB-first search for the k-th largest key T.  A prefix with EXACTLY k keys at or above it ends the search: those k keys
             // are the picks whatever the remaining bits are (no tie can straddle the cut) -- typically after ~20 of the 32 rounds.
+            DEC_TS(23);
             unsigned T = 0;
             bool exact = false;
             for (int bit = 31; bit >= 0; --bit) {
@@ -123,6 +146,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                     break;
                 }
             }
+            DEC_TS(24);
             if (exact) {
 #pragma unroll
                 for (int c = 0; c < CAND; ++c)
@@ -150,9 +174,38 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         }
     }
 
+    DEC_TS(25);
     // ---- run extraction
     my_s = 0;
     my_e = 0;
+    if (scr) {
+        unsigned long long wd[CAND];
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) wd[c] = __ballot((selbits >> c) & 1ull);
+        int n_s = 0, n_e = 0;  // runs started / ended in the words so far (wave uniform)
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            const unsigned long long w = wd[c];
+            if (w == 0ull) continue;
+            const unsigned long long below = c > 0 ? (wd[c > 0 ? c - 1 : 0] >> 63) : 0ull;             // block 64c - 1 selected
+            const unsigned long long above = c + 1 < CAND ? (wd[c + 1 < CAND ? c + 1 : c] << 63) : 0ull;  // block 64c + 64 selected
+            const unsigned long long sm = w & ~((w << 1) | below);  // blocks that start a run
+            const unsigned long long em = w & ~((w >> 1) | above);  // blocks that end one
+            const int blk = 64 * c + lane;
+            if ((sm >> lane) & 1ull)
+                scr[2 * (n_s + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u)))] = blk * l_sel;
+            if ((em >> lane) & 1ull)
+                scr[2 * (n_e + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u))) + 1] =
+                    min((blk + 1) * l_sel, t + 1);
+            n_s += __popcll(sm);
+            n_e += __popcll(em);
+        }
+        if (lane < n_s) {  // the i-th start pairs with the i-th end: runs are disjoint and ascending
+            my_s = scr[2 * lane];
+            my_e = scr[2 * lane + 1];
+        }
+        return;
+    }
     int nrun = 0;
     int cur_s = -1, cur_e = -1;  // pending run (block ids), wave uniform
     auto emit = [&]() {
@@ -186,10 +239,10 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
 
 // same, storing the row's [W,2] ranges
 template <int CAND>
-__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out) {
+__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out, int *scr = nullptr) {
     const int lane = lane_id();
     int my_s, my_e;
-    select_topn_row_regs<CAND>(P, p, t, my_s, my_e);
+    select_topn_row_regs<CAND>(P, p, t, my_s, my_e, scr);
     if (lane < P.W) {
         out[2 * lane] = my_s;
         out[2 * lane + 1] = my_e;

@@ -321,6 +321,39 @@ def test_fused_decode_scorer_equals_three_kernel_route(nv, S_ctx, B, tune):
     torch.cuda.synchronize()
     assert torch.equal(r1, r2)
     assert torch.equal(O1, O2)
+    # the fused kernel's closed-form Eq.9 taps (l = 2d, l' = 4d) against the same kernel reading the CSC
+    tune("DECODE_UNFUSED", 0)
+    tune("DECODE_STENCIL", 0)
+    O3, r3 = nv.selection_decode_step(Q, Kc, K, V, meta, 16, t)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r3)
+    assert torch.equal(O1, O3)
+
+
+@pytest.mark.parametrize("t", [5032, 5055, 16383 + 48])
+def test_fused_decode_with_a_meta_older_than_the_cache(nv, tune, t):
+    """The reference rebuilds kv.meta only when t enters a new selection block while K_cmp grows every d tokens
+    (nsa_attention.py:617-632): compressed rows newer than the meta have no CSC entry and are dropped from p_slc.  They reach only
+    the current and the previous block, both forced, so the ranges cannot depend on them: the closed-form taps
+    (which see every row) and the CSC of the old meta must select the same ranges."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(t)
+    S_now, S_old = t + 1, (t // 64) * 64 + 1  # the meta dates from the first token of the current selection block
+    meta_now, meta_old = nv.build_block_meta(S_now, 32, 16, 64, 16, 512), nv.build_block_meta(S_old, 32, 16, 64, 16, 512)
+    assert meta_old.S_sel == meta_now.S_sel and meta_old.S_cmp < meta_now.S_cmp
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).bfloat16()  # noqa: E731
+    B = 3
+    Q, Kc, K, V = mk(B, 1, 2, 6, 64), mk(B, 2, meta_now.S_cmp, 64), mk(B, 2, S_now, 64), mk(B, 2, S_now, 64)
+    tune("DECODE_STENCIL", 1)
+    O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta_old, 16, t)
+    tune("DECODE_STENCIL", 0)
+    O2, r2 = nv.selection_decode_step(Q, Kc, K, V, meta_old, 16, t)
+    O3, r3 = nv.selection_decode_step(Q, Kc, K, V, meta_now, 16, t)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2) and torch.equal(O1, O2)
+    assert torch.equal(r1, r3) and torch.equal(O1, O3)
 
 
 def test_beyond_64k_selection_matches_oracle(nv, orc):
