@@ -113,11 +113,11 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
             const int t = SP.t_rows ? SP.t_rows[row] : SP.t0 + tw0 + r;
             const float *pg = SP.p_grp + row * (int64_t)SP.S_sel;
             switch (cand) {
-                case 1: select_topn_row_regs<1>(SP, pg, t, s, e); break;
-                case 2: select_topn_row_regs<2>(SP, pg, t, s, e); break;
-                case 4: select_topn_row_regs<4>(SP, pg, t, s, e); break;
-                case 8: select_topn_row_regs<8>(SP, pg, t, s, e); break;
-                default: select_topn_row_regs<16>(SP, pg, t, s, e); break;
+                case 1: select_topn_row_regs<1>(SP, pg, t, s, e, (int *)kl); break;
+                case 2: select_topn_row_regs<2>(SP, pg, t, s, e, (int *)kl); break;
+                case 4: select_topn_row_regs<4>(SP, pg, t, s, e, (int *)kl); break;
+                case 8: select_topn_row_regs<8>(SP, pg, t, s, e, (int *)kl); break;
+                default: select_topn_row_regs<16>(SP, pg, t, s, e, (int *)kl); break;
             }
             if (lane < n) {
                 int32_t *out = SP.out + row * (int64_t)n * 2;
@@ -411,12 +411,9 @@ int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n,
     if (kss != 64 || vss != 64) return 0;  // the DMA steps through rows 128 B apart (rows of a [.., S, 64] cache are)
     const int mode = tuning(TUNE_SEL_BLOCKS);
     if (mode == 0) return 0;
-    // automatic choice (same-box A/B, profiles/r02/c_kernel_form_sweep*.txt): while the rows of a wave share most of their blocks
-    // (S_kv up to ~8 x the n*l' tokens a row selects) the block form is 9-16 % faster than the query-tile pairs; beyond that every
-    // block serves one row, the two extra waves per SIMD of the pairs matter more and they win by 5 % -- until K/V outgrows the L2s
-    // (S_kv >= 48k at n = 16): the launch is then bound by L2-miss traffic and the block form moves 7 % less of it (the three
-    // forced blocks are fetched once per 8 rows instead of once per pair)
-    if (mode < 0 && (int64_t)S_kv > (int64_t)512 * n && (int64_t)S_kv < (int64_t)3072 * n) return 0;
+    // automatic choice: the block form wherever it applies.  Same-box A/B (profiles/r02/c_kernel_form_sweep_3.txt): 5-25 % faster than the
+    // query-tile pairs from S = 1k to 64k.  (Before the selector's run extraction went lane-parallel the pairs still won by 5 % between
+    // S_kv = 8k and 48k, c_kernel_form_sweep_2.txt: the fused selector is a larger share of a wave that owns 8 rows.)
     const int tpt = 16 / h;
     int nt = (mode == 1 || mode == 2 || mode == 4) ? mode : 4;
     while (nt > 1 && nt * tpt > 32) nt >>= 1;  // ownership masks are 32 bits wide

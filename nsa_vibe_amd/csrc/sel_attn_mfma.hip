@@ -90,11 +90,11 @@ __global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P,
         const float *pg = SP.p_grp + row * (int64_t)SP.S_sel;
         int ms = 0, me = 0;
         switch (cand) {
-            case 1: select_topn_row_regs<1>(SP, pg, t, ms, me); break;
-            case 2: select_topn_row_regs<2>(SP, pg, t, ms, me); break;
-            case 4: select_topn_row_regs<4>(SP, pg, t, ms, me); break;
-            case 8: select_topn_row_regs<8>(SP, pg, t, ms, me); break;
-            default: select_topn_row_regs<16>(SP, pg, t, ms, me); break;
+            case 1: select_topn_row_regs<1>(SP, pg, t, ms, me, (int *)kl); break;
+            case 2: select_topn_row_regs<2>(SP, pg, t, ms, me, (int *)kl); break;
+            case 4: select_topn_row_regs<4>(SP, pg, t, ms, me, (int *)kl); break;
+            case 8: select_topn_row_regs<8>(SP, pg, t, ms, me, (int *)kl); break;
+            default: select_topn_row_regs<16>(SP, pg, t, ms, me, (int *)kl); break;
         }
         if (lane < SP.W) {
             int32_t *out = SP.out + row * (int64_t)SP.W * 2;

@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P
             const int t = SP.t_rows ? SP.t_rows[row] : SP.t0 + tw0 + r;
             const float *pg = SP.p_grp + row * (int64_t)SP.S_sel;
             switch (cand) {
-                case 1: select_topn_row_regs<1>(SP, pg, t, s, e); break;
-                case 2: select_topn_row_regs<2>(SP, pg, t, s, e); break;
-                case 4: select_topn_row_regs<4>(SP, pg, t, s, e); break;
-                case 8: select_topn_row_regs<8>(SP, pg, t, s, e); break;
-                default: select_topn_row_regs<16>(SP, pg, t, s, e); break;
+                case 1: select_topn_row_regs<1>(SP, pg, t, s, e, (int *)kl); break;
+                case 2: select_topn_row_regs<2>(SP, pg, t, s, e, (int *)kl); break;
+                case 4: select_topn_row_regs<4>(SP, pg, t, s, e, (int *)kl); break;
+                case 8: select_topn_row_regs<8>(SP, pg, t, s, e, (int *)kl); break;
+                default: select_topn_row_regs<16>(SP, pg, t, s, e, (int *)kl); break;
             }
             if (lane < n) {
                 int32_t *out = SP.out + row * (int64_t)n * 2;
