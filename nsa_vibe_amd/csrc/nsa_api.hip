@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "DECODE_STOP"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "DECODE_STOP"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, 0};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -561,7 +561,12 @@ int nsa_sel_select_attn_fwd(const float *p_grp, int t0, const int32_t *t_rows, i
                          ksg % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
                          S_kv > 0 && out_width >= 1 && out_width <= 64 && S_sel >= 1 && S_sel <= 1024 &&
                          (sel_attn_mfma_workspace(R, h, Dv, &ns), ns == 1);
-    if (!fast_ok) {  // two launches
+    // One launch (the selector inside the attention kernel) or two.  The fused selector runs 8 rows one after the other in a wave of a
+    // kernel held to 2 waves per SIMD by its 253 VGPRs: its scalar chains run at latency and it adds 36 / 120 / 424 us at 4k x 8 / 16k x 2 /
+    // 64k x 1, where the select kernel on its own (a row per wave, 6+ waves per SIMD) takes 28 / 57 / 243 us (profiles/r02
+    // i_selector_share.txt): two launches are the default.
+    const bool fuse = tuning(TUNE_SEL_FUSE) > 0;
+    if (!fast_ok || !fuse) {  // two launches
         if (int rc = nsa_select_topn_ranges(p_grp, R, S, G, t0, t_rows, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, ranges_out,
                                             out_width, stream))
             return rc;

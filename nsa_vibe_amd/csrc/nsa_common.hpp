@@ -44,6 +44,7 @@ enum Tune {
     TUNE_DECODE_WG,         // NSA_HIP_DECODE_WG: decode attention as one workgroup per row (+ fused into the decode scorer), -1 auto, 0 off
     TUNE_SEL_ROWSUM,        // NSA_HIP_SEL_ROWSUM: block-form forward, row sums of P by MFMA (1) or by v_add (0)
     TUNE_DECODE_STENCIL,    // NSA_HIP_DECODE_STENCIL: fused decode kernel, 1 = closed-form Eq.9 taps for l = 2d, l' = 4d; 0 = always the CSC
+    TUNE_SEL_FUSE,          // NSA_HIP_SEL_FUSE: nsa_sel_select_attn_fwd, 1 = the selector runs inside the attention launch, 0 = two launches
     TUNE_DECODE_STOP,       // NSA_HIP_DECODE_STOP: measurement aid, the fused decode kernel returns after phase N (1 logits, 2 scores, 3 top-n); 0 = run all
     TUNE_COUNT
 };

@@ -22,9 +22,14 @@ namespace nsa {
 template <int CAND>
 __global__ __launch_bounds__(256) void select_topn_kernel(SelectParams P) {
     __shared__ int scr[4][128];  // run extraction scratch, one slice per wave
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + uniform((int)(threadIdx.x >> 6));
     if (row >= P.R) return;
-    const int t = P.t_rows ? P.t_rows[row] : P.t0 + (int)((row / P.G) % P.S);
+    // one row per wave: the row and its token are scalars (and 32-bit arithmetic when the row count allows: a 64-bit division is ~100 instructions)
+    int t;
+    if (P.t_rows) t = P.t_rows[row];
+    else if (P.R < ((int64_t)1 << 31)) t = P.t0 + (int)(((unsigned)row / (unsigned)P.G) % (unsigned)P.S);
+    else t = P.t0 + (int)((row / P.G) % P.S);
+    t = uniform(t);
     select_topn_row<CAND>(P, P.p_grp + row * (int64_t)P.S_sel, t, P.out + row * (int64_t)P.W * 2, scr[threadIdx.x >> 6]);
 }
 
@@ -113,6 +118,7 @@ int select_params_sequential(SelectParams *P, int S_sel, int l_sel, int n_top, i
     P->n_forced = nf_all;
     P->keepmask = 0xffffffffu;
     P->all_valid = 0;
+    P->forced_plain = 1;
     return NSA_OK;
 }
 
@@ -129,6 +135,7 @@ int select_params_fill(SelectParams *Pp, int S_sel, int l_sel, int n_top, int fo
         P.n_forced = nf_all;
         P.keepmask = 0xffffffffu;
         P.all_valid = 0;
+        P.forced_plain = 1;
     } else if (mode == NSA_SEL_BATCHED) {
         int nfc;
         P.keepmask = batched_keepmask(S_total, l_sel, force_init, force_local, &nfc);
@@ -138,6 +145,7 @@ int select_params_fill(SelectParams *Pp, int S_sel, int l_sel, int n_top, int fo
         P.k_actual = k_rest < S_sel ? k_rest : S_sel;
         P.n_forced = k_rest > 0 ? nfc : (nfc < n_top ? nfc : n_top);
         P.all_valid = n_top >= S_sel ? 1 : 0;
+        P.forced_plain = (nfc == nf_all && P.n_forced == nf_all) ? 1 : 0;
     } else {
         NSA_CHECK_ARG(false, "select: unknown mode %d", mode);
     }

@@ -1,5 +1,7 @@
 // Top-n selection of one row by one wave (shared by select_topn_kernel and the fused decode scorer).
 #pragma once
+#include <type_traits>
+
 #include "nsa_common.hpp"
 
 #ifndef DEC_TS
@@ -18,6 +20,7 @@ struct SelectParams {
     unsigned keepmask; // batched: bit i = sorted forced column i is kept
     int all_valid;     // batched with n_top >= S_sel: select every valid block
     int l_sel_shift;   // log2(l_sel) when l_sel is a power of two, else -1 (the block of a token without an integer division)
+    int forced_plain;  // batched: every forced column is kept and used (S > 2 l'), the forced set is {0} + (cblk - force_local, cblk]
 };
 
 // one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS).  Lane i < min(W, 64) returns
@@ -31,33 +34,54 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     const int lane = lane_id();
     const int l_sel = P.l_sel, S_sel = P.S_sel;
     const int sh = P.l_sel_shift;
-    const int nvalid_blocks = min(S_sel, sh >= 0 ? (t + 1) >> sh : (t + 1) / l_sel);  // blocks j with (j+1)*l' <= t+1
+    // (t is the same for every lane: one row per wave.  Saying so keeps the slot tests below on the scalar unit)
+    const int nvalid_blocks = uniform(min(S_sel, sh >= 0 ? (t + 1) >> sh : (t + 1) / l_sel));  // blocks j with (j+1)*l' <= t+1
 
+    using mask_t = typename std::conditional<(CAND <= 32), unsigned, unsigned long long>::type;
     float key[CAND];
-    unsigned long long selbits = 0ull;  // bit c = block lane + 64 c selected
+    mask_t selbits = 0;  // bit c = block lane + 64 c selected
+    // a slot (64 blocks) that lies below the valid bound is one unpredicated load at an immediate offset from p + lane; only the slot
+    // the bound falls into is predicated per lane, and slots above it are not read at all (with causal_skip the scorer never wrote them)
+    const float *pl = p + lane;
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
         const int j = lane + 64 * c;
-        float k = -INFINITY;
-        if (j < nvalid_blocks) k = __fsub_rn(p[j], __fmul_rn((float)j, 1e-8f));
-        key[c] = k;
-        if (P.all_valid && j < nvalid_blocks) selbits |= 1ull << c;
+        float v = 0.f;
+        if (64 * c + 64 <= nvalid_blocks) v = pl[64 * c];
+        else if (64 * c < nvalid_blocks && j < nvalid_blocks) v = pl[64 * c];
+        const float k = __fsub_rn(v, __fmul_rn((float)j, 1e-8f));
+        key[c] = j < nvalid_blocks ? k : -INFINITY;
+    }
+    if (P.all_valid) {
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) selbits |= lane + 64 * c < nvalid_blocks ? (mask_t)1 << c : (mask_t)0;
     }
 
     DEC_TS(20);
     if (!P.all_valid) {
         // ---- forced blocks
-        const int cblk = max(sh >= 0 ? t >> sh : t / l_sel, 0);
+        const int cblk = uniform(max(sh >= 0 ? t >> sh : t / l_sel, 0));
         const int nf_all = (P.force_init ? 1 : 0) + P.force_local;
-        if (P.mode == NSA_SEL_SEQUENTIAL) {
-            // every entry of the forced list [0 (init)] + [max(cblk - a, 0) : a = force_local-1 .. 0] is taken, valid or not: block j is
-            // forced iff it is the initial block or lies in (cblk - force_local, cblk] (the clamp to 0 is the case force_local > cblk)
+        if (P.mode == NSA_SEL_SEQUENTIAL || P.forced_plain) {
+            // every entry of the forced list [0 (init)] + [max(cblk - a, 0) : a = force_local-1 .. 0] is taken: block j is forced iff it is
+            // the initial block or lies in (cblk - force_local, cblk] (the clamp to 0 is the case force_local > cblk).  Sequential mode
+            // keeps a forced block valid or not, batched mode drops the invalid ones (the partial current block).  The window spans one
+            // or two slots: the others skip it on the scalar unit.
+            const int keep_to = P.mode == NSA_SEL_SEQUENTIAL ? S_sel : nvalid_blocks;
+            const int lo = max(cblk - P.force_local + 1, 0), hi = min(cblk, S_sel - 1), hi_sel = min(hi, keep_to - 1);
+            if (P.force_local > 0 && lo <= hi) {
 #pragma unroll
-            for (int c = 0; c < CAND; ++c) {
-                const int j = lane + 64 * c;
-                const bool f = ((P.force_init && j == 0) || (j <= cblk && j > cblk - P.force_local)) && j < S_sel;
-                key[c] = f ? -INFINITY : key[c];  // excluded from top-k
-                selbits |= f ? 1ull << c : 0ull;
+                for (int c = 0; c < CAND; ++c) {
+                    if (64 * c > hi || 64 * c + 63 < lo) continue;
+                    const int j = lane + 64 * c;
+                    const bool f = (unsigned)(j - lo) <= (unsigned)(hi - lo);
+                    key[c] = f ? -INFINITY : key[c];  // excluded from top-k
+                    selbits |= (f && j <= hi_sel) ? (mask_t)1 << c : (mask_t)0;
+                }
+            }
+            if (P.force_init && S_sel > 0) {
+                key[0] = lane == 0 ? -INFINITY : key[0];
+                selbits |= (lane == 0 && keep_to > 0) ? (mask_t)1 : (mask_t)0;
             }
         } else {
             int used = 0;
@@ -76,8 +100,8 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
 #pragma unroll
                     for (int cc = 0; cc < CAND; ++cc)
                         if (cc == c) {
-                            key[cc] = -INFINITY;                 // excluded from top-k
-                            if (valid) selbits |= 1ull << cc;  // batched drops invalid picks
+                            key[cc] = -INFINITY;                       // excluded from top-k
+                            if (valid) selbits |= (mask_t)1 << cc;  // batched drops invalid picks
                         }
                 }
             }
@@ -150,7 +174,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
             if (exact) {
 #pragma unroll
                 for (int c = 0; c < CAND; ++c)
-                    if (u[c] >= T) selbits |= 1ull << c;
+                    if (u[c] >= T) selbits |= (mask_t)1 << c;
             } else {
                 int cnt_gt = 0;  // keys above T: fewer than k_eff by construction
 #pragma unroll
@@ -167,7 +191,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
                     const bool eq = u[c] == T;
                     const unsigned long long em = __ballot(eq);
                     const int take = min(__popcll(em), remaining);
-                    if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= 1ull << c;
+                    if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= (mask_t)1 << c;
                     remaining -= take;
                 }
             }
@@ -181,7 +205,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     if (scr) {
         unsigned long long wd[CAND];
 #pragma unroll
-        for (int c = 0; c < CAND; ++c) wd[c] = __ballot((selbits >> c) & 1ull);
+        for (int c = 0; c < CAND; ++c) wd[c] = __ballot((selbits >> c) & 1u);
         int n_s = 0, n_e = 0;  // runs started / ended in the words so far (wave uniform)
 #pragma unroll
         for (int c = 0; c < CAND; ++c) {
@@ -192,10 +216,11 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
             const unsigned long long sm = w & ~((w << 1) | below);  // blocks that start a run
             const unsigned long long em = w & ~((w >> 1) | above);  // blocks that end one
             const int blk = 64 * c + lane;
-            if ((sm >> lane) & 1ull)
-                scr[2 * (n_s + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u)))] = blk * l_sel;
-            if ((em >> lane) & 1ull)
-                scr[2 * (n_e + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u))) + 1] =
+            // (the scalar masks predicate the lanes directly; the run counts so far enter the bit counts as their start value)
+            if (__builtin_amdgcn_inverse_ballot_w64(sm))
+                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, (unsigned)n_s))] = blk * l_sel;
+            if (__builtin_amdgcn_inverse_ballot_w64(em))
+                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, (unsigned)n_e)) + 1] =
                     min((blk + 1) * l_sel, t + 1);
             n_s += __popcll(sm);
             n_e += __popcll(em);
@@ -217,7 +242,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     };
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
-        unsigned long long w = __ballot((selbits >> c) & 1ull);
+        unsigned long long w = __ballot((selbits >> c) & 1u);
         while (w) {  // maximal runs of ones of this word, ascending
             const int sb = __builtin_ctzll(w);
             const unsigned long long inv = ~(w >> sb);

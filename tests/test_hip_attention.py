@@ -309,9 +309,11 @@ def test_properties_full_size_64k(nv):
 @pytest.mark.parametrize("mode", ["batched", "sequential"])
 @pytest.mark.parametrize("B,S,G,dtype", [(2, 4096, 2, torch.bfloat16), (1, 16384, 2, torch.bfloat16), (1, 700, 3, torch.float16),
                                          (1, 300, 2, torch.float32), (1, 40, 1, torch.bfloat16)])
-def test_select_and_attend_equals_separate_calls(nv, mode, B, S, G, dtype):
-    """top-n selection inside the attention launch (MFMA route, enough rows) and its two-launch fallbacks: ranges bit-exact and
-    O identical to select_topn_ranges_{batched,rows} followed by selection_attention_hip"""
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_select_and_attend_equals_separate_calls(nv, mode, B, S, G, dtype, fuse, tune):
+    """nsa_sel_select_attn_fwd, as two launches (the default) and with the top-n selection inside the attention launch (SEL_FUSE = 1,
+    MFMA route): ranges bit-exact and O identical to select_topn_ranges_{batched,rows} followed by selection_attention_hip"""
+    tune("SEL_FUSE", fuse)
     g = torch.Generator(device="cuda")
     g.manual_seed(S + G)
     meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
@@ -404,6 +406,7 @@ def test_query_tile_kernel_long_context_second_bitmap_word_group(nv, tune):
 def test_query_tile_kernel_equals_one_row_kernel_on_selector_output(nv, mode, tune):
     """m7c geometry, ranges from the real selector (fused in the launch): all three forward kernels agree, and the fused launch
     writes the same ranges whichever kernel hosts the selector"""
+    tune("SEL_FUSE", 1)
     torch.manual_seed(3)
     B, S, G, h, D = 2, 1500, 2, 6, 64
     meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
@@ -567,6 +570,7 @@ def test_block_kernel_long_context_and_kernel_agreement(nv, tune):
 def test_block_kernel_equals_other_kernels_on_selector_output(nv, mode, tune):
     """m7c geometry, ranges from the real selector (fused in the launch): the block form (every NT) against the one-row kernel -- same
     ranges bit for bit whichever kernel hosts the selector, outputs within rounding; S not a multiple of the rows per wave"""
+    tune("SEL_FUSE", 1)
     torch.manual_seed(4)
     B, S, G, h, D = 2, 1501, 2, 6, 64
     meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
