@@ -83,29 +83,36 @@ def time_events(fn, iters, warm=2):
 
 
 def stage_times(nv, meta, Q, Kc, K, V, S, iters):
-    """per-stage HIP-event times.  The step runs scores, then ONE launch that selects and attends (the selector runs inside the
-    attention kernel): that launch is the dominant kernel of the roofline; the standalone select kernel is timed for reference."""
+    """per-stage HIP-event times.  The step runs three launches: scores, the select kernel, the selection-attention kernel (the last two
+    behind one native call, nsa_sel_select_attn_fwd).  The attention kernel is the dominant one: it carries the roofline."""
     p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
     ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
     t_sc = time_events(lambda: nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True), iters)
     t_sel = time_events(lambda: nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S), iters)
-    t_att = time_events(lambda: nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched"), iters)
+    with torch.no_grad():
+        t_att = time_events(lambda: nv.selection_attention_hip(Q, K, V, ranges), iters)
+    t_sa = time_events(lambda: nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched"), iters)
     L = (ranges[..., 1] - ranges[..., 0]).clamp_min(0).sum(-1).double()
-    return t_sc, t_sel, t_att, float(L.sum().item()), float(L.mean().item()), gathered_tiles(ranges, K.shape[2], max(1, 16 // H))
+    return t_sc, t_sel, t_att, t_sa, float(L.sum().item()), float(L.mean().item()), gathered_tiles(ranges, K.shape[2])
 
 
-def gathered_tiles(ranges, S_kv, tpw):
-    """32-key K/V tiles the query-tile kernel really brings into LDS: the union over the tpw rows one wave owns (sel_attn_rows_mfma.hip)"""
+BLK_KEYS = 64                           # keys of one K/V block of the block-form kernel (sel_attn_blocks_mfma.hip)
+BLK_ROWS = min(32, 4 * max(1, 16 // H))  # query rows one wave owns there (NT = 4 column tiles of 16 // h rows)
+
+
+def gathered_tiles(ranges, S_kv, tpw=BLK_ROWS, keys=BLK_KEYS):
+    """K/V blocks (of `keys` keys) the attention kernel really brings into LDS: the union over the tpw rows one wave owns"""
     Bq, Sq, Gq = ranges.shape[:3]
-    nt = (S_kv + 31) // 32
+    sh = keys.bit_length() - 1
+    nt = (S_kv + keys - 1) // keys
     total = 0.0
     for b in range(Bq):  # one sequence at a time: the cover map of a 64k sequence is 0.5 GB
         rb = ranges[b: b + 1]
         s, e = rb[..., 0].long().clamp(0, S_kv), rb[..., 1].long().clamp(0, S_kv)
         live = (e > s).to(torch.int16)
         diff = torch.zeros(1, Sq, Gq, nt + 1, dtype=torch.int16, device=ranges.device)
-        diff.scatter_add_(3, (s >> 5).clamp(max=nt), live)
-        diff.scatter_add_(3, (((e - 1).clamp_min(0) >> 5) + 1).clamp(max=nt), -live)
+        diff.scatter_add_(3, (s >> sh).clamp(max=nt), live)
+        diff.scatter_add_(3, (((e - 1).clamp_min(0) >> sh) + 1).clamp(max=nt), -live)
         cover = diff.cumsum(3, dtype=torch.int16)[..., :nt] > 0
         del diff
         Sp = Sq // tpw * tpw
@@ -625,8 +632,8 @@ def main():
                    "global_batch": world * B, "seq_len": S, "parallelism": f"batch x group shard over {world} GPU(s), no collective"},
     }
     if rank == 0:
-        t_sc, t_sel, t_att, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
-        gathered = n_tiles * 32 * (D + D) * 2
+        t_sc, t_sel, t_att, t_sa, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
+        gathered = n_tiles * BLK_KEYS * (D + D) * 2
         alg_bytes = Lsum * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V counted once per group
         flops = 4.0 * H * Lsum * D  # 2*h*L*Dk (QK^T) + 2*h*L*Dv (PV) per row
         tfl = flops / (t_att * 1e-3) / 1e12
@@ -636,9 +643,9 @@ def main():
                 "note": "in-block QK^T + PV flops 4*h*L*D per row over the same kernel time: the matrix pipe is far from binding here"}
         l2 = {"bound": "l2", "achieved": gathered / (t_att * 1e-3) / 1e9, "peak": L2_PEAK_GBPS, "unit": "GB/s",
               "frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS, "gathered_bytes_per_launch": gathered,
-              "note": "K/V tiles really brought into LDS (rows of one wave share a tile they both selected) vs the ~34.5 TB/s aggregate "
-                      "L2 bandwidth of the guide"}
-        common = {"kernel": "select + attend (one launch: top-n selection of the row, then its block-sparse attention)", "kernel_ms": t_att,
+              "note": "64-key K/V blocks really brought into LDS (the 8 rows of one wave share a block any of them selected) vs the "
+                      "~34.5 TB/s aggregate L2 bandwidth of the guide"}
+        common = {"kernel": "sel_attn_blocks_mfma_kernel (block-sparse selection attention over the rows' ranges)", "kernel_ms": t_att,
                   "mean_selected_tokens_per_row": Lmean, "algorithmic_gather_bytes_per_launch": alg_bytes,
                   "algorithmic_gather_GBps": alg_bytes / (t_att * 1e-3) / 1e9, "traffic": traffic}
         if traffic is not None and traffic > 0.1 * gathered:
@@ -657,9 +664,9 @@ def main():
             out["roofline"] = dict(common, **{k: v for k, v in l2.items() if k != "note"},
                                    note="K/V of a (b,g) fits its XCD's L2: the gather is L2 resident (PMC HBM traffic = `traffic`, ~compulsory), the launch "
                                         "is bound by instruction issue and the L1->LDS path; see DESIGN 4.1c", mfma=mfma)
-        out["stages_ms"] = {"scores": t_sc, "select_and_attention_one_launch": t_att, "select_standalone_kernel": t_sel,
+        out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att, "select_and_attention_one_call": t_sa,
                             "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
-                                    "so scores + select_and_attention can exceed it slightly.  select_standalone_kernel is not part of the step"}
+                                    "so the stages can sum to slightly more.  The step is three launches: scores, select, attention"}
         flops_sc = 2.0 * B * S * G * H * meta.S_cmp * D
         out["roofline_scores"] = {"kernel": "scores_mfma_kernel (fused p_cmp softmax + Eq.9 + Eq.10)", "bound": "mfma",
                                   "achieved": flops_sc / (t_sc * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -682,10 +689,10 @@ def main():
                 for S2, B2 in ((4096, 8), (4096, 1), (16384, 1), (65536, 1)):
                     m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
                     ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 5, warm=2)
-                    sc, se, at, Ls, Lm, nt2 = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 5)
-                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "tok_per_s": B2 * S2 / (ms * 1e-3), "scores_ms": sc, "select_standalone_ms": se,
-                                                    "select_and_attention_ms": at, "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9,
-                                                    "attn_gathered_GBps": nt2 * 32 * 256 / (at * 1e-3) / 1e9,
+                    sc, se, at, sa, Ls, Lm, nt2 = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 5)
+                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "tok_per_s": B2 * S2 / (ms * 1e-3), "scores_ms": sc, "select_ms": se,
+                                                    "attention_ms": at, "select_and_attention_ms": sa, "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9,
+                                                    "attn_gathered_GBps": nt2 * BLK_KEYS * 256 / (at * 1e-3) / 1e9,
                                                     "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12,
                                                     "attn_mfma_frac": 4.0 * H * Ls * D / (at * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                                     "hbm_traffic": pmc_traffic(f"S{S2}_B{B2}"),

@@ -52,8 +52,14 @@ struct MfmaS<_Float16> {
 // (16-row sub-tile, column tile); with a run-time h every one of the 15 possible adds is its own two-instruction basic block
 // behind a scalar compare and branch (16 blocks x 16 sub-tiles per K_cmp tile: the second sweep cost 2.4x the first per tile,
 // profiles/r01 e_pmc: 543 vs 222 VALU per wave and tile), with HC the sum is straight-line code.
+// FLAT (HC = 6 with NT = 3): the 48 columns of a wave's three tiles are the 8 x 6 (query, head) pairs of 8 queries laid end to end, instead
+// of 2 queries (12 of 16 columns) per tile and four tiles: a quarter fewer MFMAs, exponentials and adds for the same 8 queries.  On gfx950
+// MFMA and VALU issue do not overlap on a SIMD (tools/ubench/issue_rates.hip: 4 MFMA + 8 FMA take 90 cycles, 67 + 31 apart), so the time of
+// this kernel is the SUM of its MFMA and VALU cycles and every unused column costs both.  Queries 2 and 5 of the eight straddle two tiles:
+// their head sum takes the tail of one tile's shifted sums and the head of the next one's (one more DPP add each).
 template <typename T, int D, int NT, int HC>
 __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
+    constexpr bool FLAT = (HC == 6 && NT == 3);
     using M = MfmaS<T>;
     using x8 = typename M::x8;
     constexpr int ROWB = D * 2;
@@ -69,8 +75,9 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     const int wave = uniform(tid >> 6);
     const int rho = lane & 15, q = lane >> 4;
     const int h = HC ? HC : P.h;
-    const int QPT = 16 / h;              // queries per 16-column tile
-    const int QW = 4 * NT * QPT;         // queries per workgroup
+    const int QPT = 16 / h;                          // queries per 16-column tile
+    const int QPW = FLAT ? 8 : NT * QPT;             // queries per wave
+    const int QW = 4 * QPW;                          // queries per workgroup
     const int bg = blockIdx.y;
     const int b = bg / P.G, g = bg % P.G;
     // late query tiles first: with causal_skip the second sweep of a tile grows with its position (a tile at the end of a 64k sequence does
@@ -84,10 +91,11 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     int tq[NT];  // query of this lane's column (or -1)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int qi = rho / h;  // query within the tile
-        const int hh = rho % h;
-        const int t = t0 + (wave * NT + n) * QPT + qi;
-        const bool ok = qi < QPT && t < P.S;
+        const int col = FLAT ? 16 * n + rho : rho;  // FLAT: column of the wave's 48, else column of the tile
+        const int qi = col / h;                      // query within the wave (FLAT) / the tile
+        const int hh = col % h;
+        const int t = FLAT ? t0 + wave * QPW + qi : t0 + (wave * NT + n) * QPT + qi;
+        const bool ok = (FLAT || qi < QPT) && t < P.S;
         tq[n] = ok ? t : -1;
         const T *qr = (const T *)P.Q + ((((int64_t)b * P.S + (ok ? t : 0)) * P.G + g) * h + hh) * (int64_t)D;
 #pragma unroll
@@ -158,13 +166,24 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
             // common path: every lane keeps its own reference max and only accumulates sum(exp2(x - m)); no max, no
             // mask, no rescale.  All 16 exponents are <= 12 whenever the sum stays <= 2^12, so the sum itself is the
             // test: a larger (or inf/nan: first tile, m = -inf) sum, or a padded last tile, takes the exact slow path.
-            float sum = 0.f;
+            // packed fp32: one v_pk_fma_f32 forms two exponents and one v_pk_add_f32 adds two terms (the exp itself stays scalar): 4 VALU
+            // instructions per two logits instead of 6 in a kernel bound by VALU issue.  Two partial sums, added at the end.
+            f32x2 sum2 = {0.f, 0.f};
+            const f32x2 c22 = {c2, c2}, nm2 = {-mrun[n], -mrun[n]};
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sum += __builtin_amdgcn_exp2f(fmaf(acc[u][n][j], c2, -mrun[n]));
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 x2 = {acc[u][n][j], acc[u][n][j + 1]};
+                    const f32x2 t2 = __builtin_elementwise_fma(x2, c22, nm2);
+                    const f32x2 e2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                    sum2 += e2;
+                }
+            float sum = sum2[0] + sum2[1];
             if (__any(!(sum <= 4096.f)) || rows_valid < TILE_ROWS) {
                 asm volatile("; sweep-1 slow path" ::: "memory");
+                int rv = rows_valid;  // (same reason as for the logits below: the 16 row masks belong to this block)
+                asm volatile("" : "+s"(rv));
                 float v[16];
                 float mx = -INFINITY;
 #pragma unroll
@@ -172,7 +191,11 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 16 * u + 4 * q + j;
-                        const float x = (r < rows_valid) ? acc[u][n][j] * c2 : -INFINITY;
+                        // the logit enters this block through an (empty) asm: without it the compiler evaluates the masks, products and maxima
+                        // of this rare path ahead of the branch, on every tile (90 of 255 VALU instructions of the common path)
+                        float a = acc[u][n][j];
+                        asm volatile("" : "+v"(a));
+                        const float x = (r < rv) ? a * c2 : -INFINITY;
                         v[4 * u + j] = x;
                         mx = fmaxf(mx, x);
                     }
@@ -227,15 +250,24 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = 16 * tile + 4 * u + q;  // selection block of this lane group
+            float slcs[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 float p[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p[k] = __builtin_amdgcn_exp2f(fmaf(acc[u][n][k], c2, -mlog[n]));
-                if (rows_valid < TILE_ROWS) {  // padded last tile only (wave uniform)
+                for (int k = 0; k < 4; k += 2) {
+                    const f32x2 x2 = {acc[u][n][k], acc[u][n][k + 1]}, c22 = {c2, c2}, nm2 = {-mlog[n], -mlog[n]};
+                    const f32x2 t2 = __builtin_elementwise_fma(x2, c22, nm2);
+                    p[k] = __builtin_amdgcn_exp2f(t2[0]);
+                    p[k + 1] = __builtin_amdgcn_exp2f(t2[1]);
+                }
+                if (rows_valid < TILE_ROWS) {  // padded last tile only (wave uniform).  rv: the row masks stay inside this block (left to
+                                               // the compiler they are formed and applied on every tile: 8 of 36 VALU per sub-tile)
+                    int rv = rows_valid;
+                    asm volatile("" : "+s"(rv));
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (16 * u + 4 * q + k >= rows_valid) p[k] = 0.f;
+                        if (16 * u + 4 * q + k >= rv) p[k] = 0.f;
                 }
                 // 1/2 p[4j-1]: register 3 of the previous lane group (previous sub-tile for q == 0)
                 const float rot = __shfl(p[3], (lane + 48) & 63, 64);
@@ -245,16 +277,56 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
                 slc += p[1];
                 slc += p[2];
                 slc = fmaf(0.5f, p[3], slc);
-                // Eq.10: heads of one query are h consecutive lanes of the 16-lane row; ascending-h sum with DPP row
-                // shifts (lane i reads lane i+k of its row), no LDS crossbar traffic
-                float grp = slc;
+                slcs[n] = slc;
+            }
+            // Eq.10: heads of one query are h consecutive columns: ascending-h sum with DPP row shifts (lane i reads lane i+k of its row, 0
+            // past the row's end), no LDS crossbar traffic.  v_add_f32 with the shift on its first operand: one instruction per head (the
+            // compiler keeps a v_mov_b32_dpp and an add apart).  s_nop 1: a DPP read of a VGPR the previous VALU instruction wrote needs two
+            // wait states, and inline assembly is outside the compiler's hazard bookkeeping.  Outputs are early-clobber: they must not
+            // share a register with an input a later step still reads.
+            float grps[NT];
+#define NSA_HS1 "s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define NSA_HSA(K) "v_add_f32_dpp %0, %1, %0 row_shl:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define NSA_HSB(K) "v_add_f32_dpp %0, %1, %2 row_shl:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            if constexpr (FLAT) {
+                // columns 16 n + rho = 6 query + head.  Query starts: tile 0 lanes 0, 6, 12 (12: heads 0-3 here, 4-5 = lanes 0-1 of tile 1);
+                // tile 1 lanes 2, 8, 14 (14: heads 0-1 here, 2-5 = lanes 0-3 of tile 2); tile 2 lanes 4, 10.
+                float s0, t1, s1, t2, s2;
+                asm volatile(NSA_HS1 NSA_HSA(2) NSA_HSA(3) NSA_HSA(4) NSA_HSA(5) : "=&v"(s0) : "v"(slcs[0]));
+                asm volatile(NSA_HS1 : "=&v"(t1) : "v"(slcs[1]));                                            // lane 0: heads 4 + 5 of query 2
+                asm volatile(NSA_HSB(2) NSA_HSA(3) NSA_HSA(4) NSA_HSA(5) : "=&v"(s1) : "v"(slcs[1]), "v"(t1));
+                asm volatile(NSA_HS1 NSA_HSA(2) NSA_HSA(3) : "=&v"(t2) : "v"(slcs[2]));                      // lane 0: heads 2 .. 5 of query 5
+                asm volatile(NSA_HSB(4) NSA_HSA(5) : "=&v"(s2) : "v"(slcs[2]), "v"(t2));
+                // the straddling queries: lane 12 of tile 0 adds lane 0 of t1, lane 14 of tile 1 adds lane 0 of t2 (other lanes: + 0 or unused)
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:12 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" : "=&v"(grps[0]) : "v"(t1), "v"(s0));
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:14 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" : "=&v"(grps[1]) : "v"(t2), "v"(s1));
+                grps[2] = s2;
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float slc = slcs[n];
+                    float grp = slc;
+                    if constexpr (HC == 4) asm volatile(NSA_HS1 NSA_HSA(2) NSA_HSA(3) : "=&v"(grp) : "v"(slc));
+                    else if constexpr (HC == 6) asm volatile(NSA_HS1 NSA_HSA(2) NSA_HSA(3) NSA_HSA(4) NSA_HSA(5) : "=&v"(grp) : "v"(slc));
+                    else if constexpr (HC == 8) asm volatile(NSA_HS1 NSA_HSA(2) NSA_HSA(3) NSA_HSA(4) NSA_HSA(5) NSA_HSA(6) NSA_HSA(7) : "=&v"(grp) : "v"(slc));
+                    else {
 #define NSA_HS(K) \
     if (K < h) grp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, slc), 0x100 | K, 0xf, 0xf, true));
-                NSA_HS(1) NSA_HS(2) NSA_HS(3) NSA_HS(4) NSA_HS(5) NSA_HS(6) NSA_HS(7) NSA_HS(8)
-                NSA_HS(9) NSA_HS(10) NSA_HS(11) NSA_HS(12) NSA_HS(13) NSA_HS(14) NSA_HS(15)
+                        NSA_HS(1) NSA_HS(2) NSA_HS(3) NSA_HS(4) NSA_HS(5) NSA_HS(6) NSA_HS(7) NSA_HS(8)
+                        NSA_HS(9) NSA_HS(10) NSA_HS(11) NSA_HS(12) NSA_HS(13) NSA_HS(14) NSA_HS(15)
 #undef NSA_HS
-                if (tq[n] >= 0 && (rho % h) == 0 && j <= jlast)
-                    P.p_grp[(((int64_t)b * P.S + tq[n]) * P.G + g) * (int64_t)P.S_sel + j] = grp;
+                    }
+                    grps[n] = grp;
+                }
+            }
+#undef NSA_HSB
+#undef NSA_HSA
+#undef NSA_HS1
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bool first_head = FLAT ? ((16 * n + rho) % h) == 0 : (rho % h) == 0;
+                if (tq[n] >= 0 && first_head && j <= jlast)
+                    P.p_grp[(((int64_t)b * P.S + tq[n]) * P.G + g) * (int64_t)P.S_sel + j] = grps[n];
             }
         }
         if (tile + 1 < tiles2) store_tile(buf ^ 1);
@@ -271,14 +343,18 @@ bool scores_mfma_supported(int dtype, int h, int Dk, int l, int d, int l_sel) {
 template <typename T, int D>
 static int launch_scores_t(const ScoresMfmaParams &P, hipStream_t st) {
     constexpr int NT = 4;
-    const int QPT = 16 / P.h;
-    const int QW = 4 * NT * QPT;
+    const bool flat = P.h == 6 && tuning(TUNE_SCORES_FORM) != 0;  // 8 queries per wave on 3 column tiles instead of 4 (A/B switch: 0 = 4 tiles)
+    const int QW = flat ? 32 : 4 * NT * (16 / P.h);
     dim3 grid((unsigned)((P.S + QW - 1) / QW), (unsigned)(P.B * P.G));
-    switch (P.h) {  // the common group sizes get straight-line head sums
-        case 6: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 6>), grid, dim3(256), 0, st, P); break;
-        case 4: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 4>), grid, dim3(256), 0, st, P); break;
-        case 8: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 8>), grid, dim3(256), 0, st, P); break;
-        default: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 0>), grid, dim3(256), 0, st, P); break;
+    if (flat) {
+        hipLaunchKernelGGL((scores_mfma_kernel<T, D, 3, 6>), grid, dim3(256), 0, st, P);
+    } else {
+        switch (P.h) {  // the common group sizes get straight-line head sums
+            case 6: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 6>), grid, dim3(256), 0, st, P); break;
+            case 4: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 4>), grid, dim3(256), 0, st, P); break;
+            case 8: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 8>), grid, dim3(256), 0, st, P); break;
+            default: hipLaunchKernelGGL((scores_mfma_kernel<T, D, NT, 0>), grid, dim3(256), 0, st, P); break;
+        }
     }
     NSA_LAUNCH_CHECK("scores_mfma");
     return NSA_OK;
