@@ -43,8 +43,13 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 
 // RS: row sums of P on the matrix pipe (l += ones . P^T: 2 MFMAs per tile instead of 16 v_add; the pipe is ~18 % busy, the VALU is the
 // bound) -- the sum then runs over the bf16 P the PV product uses, and every lane holds the whole column sum (no cross-lane step at the end)
-template <typename T, int NT, bool RS>
+// FLAT (h = 6, NT = 3): the 48 columns of the wave's three tiles are the 8 x 6 (row, head) pairs of its 8 query rows laid end to end, instead of
+// 2 rows (12 of 16 columns) per tile and four tiles.  MFMA and VALU issue do not overlap on a gfx950 SIMD (tools/ubench/issue_rates.hip), so
+// the idle quarter of every tile cost both its MFMAs and its softmax arithmetic.  Rows 2 and 5 straddle two tiles: every column keeps its own
+// running max / sum / output (a column is one (row, head) pair either way), only the ownership masks see the difference.
+template <typename T, int NT, bool RS, bool FLAT>
 __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
+    static_assert(!FLAT || NT == 3, "the flat layout is 3 tiles of 16 columns = 8 rows x 6 heads");
     using namespace blk;
     using M = MfmaT<T>;
     using x8 = typename M::x8;
@@ -53,8 +58,8 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     const int lane = lane_id();
     const int wave = uniform((int)(threadIdx.x >> 6));
     const int h = P.h, NW = P.nw, n = P.n;
-    const int tpt = P.tpw;       // rows per column tile (16 / h)
-    const int tpw = NT * tpt;    // rows per wave
+    const int tpt = P.tpw;                 // rows per column tile (16 / h)
+    const int tpw = FLAT ? 8 : NT * tpt;   // rows per wave
     const int ngrp = (P.S + tpw - 1) / tpw;  // row groups per (b,g)
     const int nbg = (int)(P.R / P.S);
     const int W4 = (ngrp + 3) >> 2;  // workgroups per (b,g)
@@ -81,21 +86,22 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
 
     // ---- per-slot constants; the Q loads go out first so that their latency runs under the range / bitmap work below
     const int rho = lane & 15, q = lane >> 4;
-    const int tsub = rho / h, head = rho - tsub * h;  // row inside the column tile, head
-    // bit of the slot's row in the ownership masks (0 for an unused slot) = (tsbit << nn*tpt) & usedmask: two VALU ops where it is needed
-    // instead of NT registers (the kernel sits at the 256-VGPR budget)
-    const unsigned tsbit = tsub < tpt ? (1u << tsub) : 0u;
+    // column -> (row of the wave, head): FLAT column 16 nn + rho = 6 row + head; else rho = h tsub + head with row = nn tpt + tsub
+    auto col_row = [&](int nn) -> int { return FLAT ? (16 * nn + rho) / 6 : nn * tpt + rho / h; };
+    auto col_head = [&](int nn) -> int { return FLAT ? (16 * nn + rho) % 6 : rho % h; };
+    auto col_used = [&](int nn) -> bool { return FLAT ? col_row(nn) < ntok : (rho / h < tpt && col_row(nn) < ntok); };
+    // bit of the column's row in the ownership masks (0 for an unused column): a few VALU ops where it is needed instead of NT registers
     const unsigned usedmask = span(0, ntok - 1);
-    auto rowbit = [&](int nn) -> unsigned { return (tsbit << (nn * tpt)) & usedmask; };
+    auto rowbit = [&](int nn) -> unsigned { return col_used(nn) ? (1u << col_row(nn)) : 0u; };
     unsigned nmask[NT];   // rows of column tile nn (wave uniform)
     x8 qf[NT][KS];
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
-        const int tok = nn * tpt + tsub;
-        const bool used = tsub < tpt && tok < ntok;
-        const int r_lo = nn * tpt, r_hi = min(nn * tpt + tpt, ntok) - 1;
+        const int tok = col_row(nn), head = col_head(nn);
+        const bool used = col_used(nn);
+        const int r_lo = FLAT ? (16 * nn) / 6 : nn * tpt, r_hi = min(FLAT ? (16 * nn + 15) / 6 : nn * tpt + tpt - 1, ntok - 1);
         nmask[nn] = r_lo <= r_hi ? span(r_lo, r_hi) : 0u;
-        const int64_t orow = (((int64_t)b * P.S + tw0 + tok) * P.G + g) * h + head;
+        const int64_t orow = (((int64_t)b * P.S + tw0 + (used ? tok : 0)) * P.G + g) * h + head;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             u32x4 raw = {0u, 0u, 0u, 0u};
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
             qf[nn][s] = __builtin_bit_cast(x8, raw);
         }
     }
+    (void)usedmask;
 
     // ---- (1) bitmaps cleared, ranges of the rows -> LDS (from the fused selector or the ranges tensor)
     for (int i = lane; i < 2 * tpw * NW + 2 * tpw; i += 64) fullw[i] = 0u;
@@ -326,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
             } else {
                 unsigned lo32 = on ? 0xffffffffu : 0u, hi32 = lo32;
                 if (partm & rbit) {
-                    lo32 = kmask[2 * (nn * tpt + tsub)];
-                    hi32 = kmask[2 * (nn * tpt + tsub) + 1];
+                    lo32 = kmask[2 * col_row(nn)];
+                    hi32 = kmask[2 * col_row(nn) + 1];
                 }
                 lo32 >>= 4 * q;
                 hi32 >>= 4 * q;
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
             ltot += __shfl_xor(ltot, 32, 64);
         }
         if (!rowbit(nn)) continue;
-        const int64_t orow = (((int64_t)b * P.S + tw0 + nn * tpt + tsub) * P.G + g) * h + head;
+        const int64_t orow = (((int64_t)b * P.S + tw0 + col_row(nn)) * P.G + g) * h + col_head(nn);
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
         T *Or = (T *)P.O + orow * D;
 #pragma unroll
@@ -424,10 +431,10 @@ int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n,
     return nt;
 }
 
-template <typename T, int NT>
+template <typename T, int NT, bool FLAT>
 static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
     SelAttnParams P = P0;
-    const int tpt = 16 / P.h, tpw = NT * tpt;
+    const int tpt = 16 / P.h, tpw = FLAT ? 8 : NT * tpt;
     P.tpw = tpt;
     P.nw = ((P.S_kv + 63) / 64 + 31) / 32;
     P.nsplit = 1;
@@ -452,7 +459,7 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
         cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
     }
     void (*k)(SelAttnParams, SelectParams, int) =
-        tuning(TUNE_SEL_ROWSUM) ? sel_attn_blocks_mfma_kernel<T, NT, true> : sel_attn_blocks_mfma_kernel<T, NT, false>;
+        tuning(TUNE_SEL_ROWSUM) ? sel_attn_blocks_mfma_kernel<T, NT, true, FLAT> : sel_attn_blocks_mfma_kernel<T, NT, false, FLAT>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_blocks_mfma");
@@ -460,14 +467,22 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
 }
 
 int launch_sel_attn_blocks_mfma(const SelAttnParams &P, int dtype, int nt, hipStream_t st) {
+    // 8 rows per wave with h = 6: three fully used column tiles instead of four with 12 of 16 columns.  It pays while the rows of a wave share
+    // their blocks (every tile of a block is computed anyway: -10 % at 2k, -8 % at 4k); once a block belongs to one row (S_kv >> n l') the
+    // four-tile form computes the one tile of that row and skips three, the flat form needs two tiles for the straddling rows 2 and 5
+    // (+3 % at 16k, +4..10 % at 64k; same-box A/B, profiles/r02/k_flat_columns.txt).  TUNE_SEL_FLAT: -1 this rule, 0 never, 1 always.
+    const int fmode = tuning(TUNE_SEL_FLAT);
+    const bool flat = nt == 4 && P.h == 6 && (fmode > 0 || (fmode < 0 && (int64_t)P.S_kv <= (int64_t)384 * P.n));
     if (dtype == NSA_DT_BF16) {
-        if (nt == 4) return launch_blocks_t<__bf16, 4>(P, st);
-        if (nt == 2) return launch_blocks_t<__bf16, 2>(P, st);
-        return launch_blocks_t<__bf16, 1>(P, st);
+        if (flat) return launch_blocks_t<__bf16, 3, true>(P, st);
+        if (nt == 4) return launch_blocks_t<__bf16, 4, false>(P, st);
+        if (nt == 2) return launch_blocks_t<__bf16, 2, false>(P, st);
+        return launch_blocks_t<__bf16, 1, false>(P, st);
     }
-    if (nt == 4) return launch_blocks_t<_Float16, 4>(P, st);
-    if (nt == 2) return launch_blocks_t<_Float16, 2>(P, st);
-    return launch_blocks_t<_Float16, 1>(P, st);
+    if (flat) return launch_blocks_t<_Float16, 3, true>(P, st);
+    if (nt == 4) return launch_blocks_t<_Float16, 4, false>(P, st);
+    if (nt == 2) return launch_blocks_t<_Float16, 2, false>(P, st);
+    return launch_blocks_t<_Float16, 1, false>(P, st);
 }
 
 }  // namespace nsa
