@@ -9,6 +9,7 @@ from . import _lib  # noqa: F401
 from .band_attention import (  # noqa: F401
     band_attention_hip,
     batched_causal_attention_compressed,
+    batched_causal_attention_compressed_first_key_parity,
     sliding_window_attention,
 )
 from .block_index import BlockMeta, build_block_meta, build_block_starts, build_M_csl_csr  # noqa: F401

@@ -118,3 +118,17 @@ def batched_causal_attention_compressed(Q, K_cmp, V_cmp, l: int, d: int, *, t0: 
                                         variant: int = 0):
     """Keys [0, num_cmp(t)), num_cmp(t) = 0 if t+1 < l else (t+1-l)//d + 1, clamped to S_cmp (attention_kernels.py:118-121)."""
     return band_attention_hip(Q, K_cmp, V_cmp, t0=t0, a=int(l), dd=int(d), c=1, w=_W_INF, scale=scale, variant=variant)
+
+
+def batched_causal_attention_compressed_first_key_parity(Q, K_cmp, V_cmp, l: int, d: int, *, t0: int = 0):
+    """PARITY MODE, opt-in: what the reference's own batched_causal_attention_compressed returns on CPU (attention_kernels.py:106-143).
+    It evaluates every token through SDPA(is_causal=True) with ONE query (:139-141), so only compressed token 0 is visible:
+    O[b,t,g,h,:] = V_cmp[b,g,0] when num_cmp(t) > 0, zeros otherwise (max |quirk - true softmax| ~ 5 on random inputs: g13 goldens keep it as
+    O_ref_quirk).  The same first-key rule as the selection branch's packed executor, so it runs on nsa_sel_attn_first_key_parity with the
+    single range [0, num_cmp(t)) per row.  Q and K_cmp do not influence the result.  Inference only."""
+    from .selection_attention import selection_attention_first_key_parity
+
+    B, S, G = Q.shape[:3]
+    rg = band_ranges(S, K_cmp.shape[2], int(t0), int(l), int(d), 1, _W_INF, Q.device)  # [S, 2]: [0, num_cmp(t))
+    ranges = rg.view(1, S, 1, 1, 2).expand(B, S, G, 1, 2).contiguous()
+    return selection_attention_first_key_parity(Q, K_cmp, V_cmp, ranges)

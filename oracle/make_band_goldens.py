@@ -6,8 +6,11 @@
   g13_win_*  reference sliding_window_attention(Q,K,V,w)  (nsa/core/attention_kernels.py:146-178) on seeded inputs.
   g13_cmp_*  compressed branch: torch SDPA under the reference's mask `col < num_cmp(t)` (attention_kernels.py:118-123).
              The reference's own CPU function evaluates it per token through SDPA(is_causal=True) with a single query,
-             which attends key 0 only (:139-141) -- its output is stored too (`O_ref_quirk`) but is NOT the parity target;
-             the target is the mask the reference states, evaluated with a true softmax ("formula pinned").
+             which attends key 0 only (:139-141) -- its output is stored too (`O_ref_quirk`; bit-exact target of the opt-in parity
+             mode batched_causal_attention_compressed_first_key_parity) but is NOT the parity target of the kernel;
+             the target is the mask the reference states, evaluated with a true softmax.  Round 2: that output is also produced by a
+             REFERENCE function -- grouped_selection_attention_masked (:705-772) on K_cmp / V_cmp with the single range
+             [0, num_cmp(t)) per row -- and stored as `O_ref_selection_masked`: the kernel is pinned to it.
 Only inputs and outputs are written.  The oracle restatement is checked against every vector before saving.
 """
 import os
@@ -26,7 +29,8 @@ sys.dont_write_bytecode = True
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-from nsa.core.attention_kernels import batched_causal_attention_compressed, sliding_window_attention  # noqa: E402
+from nsa.core.attention_kernels import (batched_causal_attention_compressed, grouped_selection_attention_masked,  # noqa: E402
+                                        sliding_window_attention)
 
 from oracle import nsa_oracle as orc  # noqa: E402
 
@@ -83,8 +87,17 @@ for name, seed, B, S, G, h, Dk, Dv, l, d in cmp_cases:
         O = np.zeros((B, S, G, h, Dv), np.float32)
     Oo = orc.batched_causal_attention_compressed(Q, K, V, l, d)
     err = float(np.abs(O - Oo).max())
-    print(f"g13_cmp_{name}: S={S} S_cmp={S_cmp}  max|sdpa(mask)-oracle| = {err:.2e}   max|quirk - true| = {np.abs(O_quirk - O).max():.2e}")
-    assert err < 2e-5
+    # the same attention through the reference's masked selection executor: one range [0, num_cmp(t)) per row over the compressed tokens
+    rg = torch.zeros(B, S, G, 1, 2, dtype=torch.int32)
+    rg[..., 0, 1] = num_cmp.view(1, S, 1).to(torch.int32)
+    if S_cmp > 0:
+        O_masked = grouped_selection_attention_masked(tQ, tK, tV, rg).numpy()
+    else:
+        O_masked = np.zeros((B, S, G, h, Dv), np.float32)
+    err_m = float(np.abs(O_masked - Oo).max())
+    print(f"g13_cmp_{name}: S={S} S_cmp={S_cmp}  max|sdpa(mask)-oracle| = {err:.2e}  max|reference masked executor - oracle| = {err_m:.2e}"
+          f"   max|quirk - true| = {np.abs(O_quirk - O).max():.2e}")
+    assert err < 2e-5 and err_m < 2e-5
     np.savez_compressed(os.path.join(OUT, f"g13_cmp_{name}.npz"), Q=Q, K=K, V=V, l=np.int32(l), d=np.int32(d), O=O,
-                        O_ref_quirk=O_quirk, num_cmp=num_cmp.numpy().astype(np.int32))
+                        O_ref_selection_masked=O_masked, O_ref_quirk=O_quirk, num_cmp=num_cmp.numpy().astype(np.int32))
 print("done")

@@ -74,8 +74,19 @@ def test_golden_compressed(nv, orc, name, dtype):
     band = dict(a=int(g["l"]), dd=int(g["d"]), c=1)
     got = check(nv, orc, g["Q"], g["K"], g["V"], dtype, 0, band)
     assert np.abs(got - g["O"]).max() <= (1e-3 if dtype == torch.float32 else 6e-2)
+    # the same output from a reference function: its masked selection executor over the compressed tokens, range [0, num_cmp(t)) per row
+    assert np.abs(got - g["O_ref_selection_masked"]).max() <= (1e-3 if dtype == torch.float32 else 6e-2)
     O2 = nv.batched_causal_attention_compressed(dev(g["Q"], dtype), dev(g["K"], dtype), dev(g["V"], dtype), int(g["l"]), int(g["d"]))
     assert np.array_equal(O2.float().cpu().numpy(), got)
+    # opt-in parity mode: the reference's own CPU result (key 0 only), bit for bit
+    if g["K"].shape[2] > 0:
+        Oq = nv.batched_causal_attention_compressed_first_key_parity(dev(g["Q"], dtype), dev(g["K"], dtype), dev(g["V"], dtype),
+                                                                     int(g["l"]), int(g["d"]))
+        want = torch.from_numpy(g["O_ref_quirk"]).to(dtype) if dtype != torch.float32 else torch.from_numpy(g["O_ref_quirk"])
+        if dtype == torch.float32:
+            assert np.array_equal(Oq.cpu().numpy(), g["O_ref_quirk"])
+        else:  # V rounded to the activation dtype first, then copied: equals the rounded reference output
+            assert torch.equal(Oq.cpu(), want)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -200,6 +200,9 @@ def test_g13_compressed(orc, name):
     assert np.array_equal(rg[:, 1], g["num_cmp"]) and not rg[:, 0].any()
     O = orc.batched_causal_attention_compressed(g["Q"], g["K"], g["V"], int(g["l"]), int(g["d"]))
     assert np.abs(O - g["O"]).max() <= 2e-5
+    # ... and == the REFERENCE's masked selection executor run on the compressed tokens with the range [0, num_cmp(t)) per row
+    # (grouped_selection_attention_masked, attention_kernels.py:705-772): the compressed branch is pinned to a reference function
+    assert np.abs(O - g["O_ref_selection_masked"]).max() <= 2e-5
     if name == "b":
         assert not O.any()
 
