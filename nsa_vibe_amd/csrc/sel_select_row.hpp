@@ -145,6 +145,20 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         // counts are capped just above k: the search needs "at least k", and "exactly k" ends it early
         auto count_ge = [&](unsigned cand, int cap) -> int {
             int cnt = 0;
+            if constexpr (SORTED && CAND >= 2) {
+                // slots 0 and 1 in straight-line code (most rounds end there: one exit test instead of four), then slot by slot
+                const unsigned long long b0 = __ballot(w[0] >= cand), b1 = __ballot(w[1] >= cand);
+                cnt = __popcll(b0) + __popcll(b1);
+                if (b1 == 0ull || cnt > cap) return cnt;  // (b0 == 0 implies b1 == 0: the slots are sorted per lane)
+#pragma unroll
+                for (int c = 2; c < CAND; ++c) {
+                    const unsigned long long b = __ballot(w[c] >= cand);
+                    if (b == 0ull) break;
+                    cnt += __popcll(b);
+                    if (cnt > cap) break;  // exact while <= cap
+                }
+                return cnt;
+            }
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {
                 const unsigned long long b = __ballot(w[c] >= cand);
