@@ -326,10 +326,16 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
                 // every slot is all-on or all-off: the softmax offset carries the mask (s*c2 - inf = -inf)
                 vbits = on ? 0xffffu : 0u;
                 const float mneg = on ? -mrun[nn] : -INFINITY;
+                const f32x2 c22 = {c2, c2}, mn2 = {mneg, mneg};  // two exponents per v_pk_fma_f32 (4.9 cycles against 2 x 3.9)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x[4 * u + j] = fmaf(sacc[u][j], c2, mneg);
+                    for (int j = 0; j < 4; j += 2) {
+                        const f32x2 s2 = {sacc[u][j], sacc[u][j + 1]};
+                        const f32x2 t2 = __builtin_elementwise_fma(s2, c22, mn2);
+                        x[4 * u + j] = t2[0];
+                        x[4 * u + j + 1] = t2[1];
+                    }
             } else {
                 unsigned lo32 = on ? 0xffffffffu : 0u, hi32 = lo32;
                 if (partm & rbit) {
