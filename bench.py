@@ -14,7 +14,8 @@ Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequence
 path (weak scaling); time = max over ranks.
 
 The JSON line also carries
-  roofline         dominant kernel of the step (select + attend, one launch).  In prefill every K/V row is gathered many times:
+  roofline         dominant kernel of the step (the selection-attention kernel; the step is three launches: scores, select,
+                   attention).  In prefill every K/V row is gathered many times:
                    at S=65536 a (b,g)'s K/V (16 MiB) exceeds an XCD's 4 MiB L2, a third of the gathered bytes miss, and the launch is
                    bound by that L2-miss traffic -- bound "hbm": HBM-side bytes per launch (rocprofv3 PMC, profiles/r02/traffic_*.json,
                    same shape) / HIP-event kernel time vs the 8 TB/s peak.  The algorithmic gather rate (> peak: cache reuse), the

@@ -321,9 +321,10 @@ NSA_API int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, 
 
 /* ---------------------------------------------------------------------------------------
  * Top-n selection + selection attention in one call (prefill): the arguments of nsa_select_topn_ranges followed by those of
- * nsa_sel_attn_fwd; ranges_out [B,S,G,out_width,2] is produced AND consumed.  On the MFMA route with enough rows the selection
- * runs inside the attention kernel (one launch); otherwise the two kernels are launched back to back.  Results are those
- * of the two separate calls, bit for bit.
+ * nsa_sel_attn_fwd; ranges_out [B,S,G,out_width,2] is produced AND consumed.  The select kernel and the attention kernel are
+ * launched back to back on the stream (the default since round 2: the selector is faster as its own launch); with the tuning
+ * switch SEL_FUSE = 1 the selection runs inside the attention kernel on the MFMA route (one launch).  Results are those of the
+ * two separate calls, bit for bit, either way.
  * ------------------------------------------------------------------------------------- */
 NSA_API int nsa_sel_select_attn_fwd(const float *p_grp, int t0, const int32_t *t_rows, int S_sel, int l_sel, int n_top, int force_init,
                             int force_local, int mode, int S_total, int32_t *ranges_out, int out_width, const void *Q, const void *K,

@@ -198,7 +198,8 @@ def select_and_attend(p_grp: torch.Tensor, Q: torch.Tensor, K: torch.Tensor, V: 
                       mode: str = "batched", t0: int = 0, force_init: bool = True, force_local: int = 2,
                       scale: Optional[float] = None, return_lse: bool = False):
     """Prefill (inference): top-n selection from the group scores and the selection attention in ONE native call
-    (nsa_sel_select_attn_fwd; on the MFMA route the selector runs inside the attention kernel).  p_grp [B,S,G,S_sel] fp32.
+    (nsa_sel_select_attn_fwd: the select kernel and the attention kernel back to back, or -- tuning switch SEL_FUSE = 1 -- the selector
+    inside the attention kernel on the MFMA route).  p_grp [B,S,G,S_sel] fp32.
     mode "batched" = select_topn_ranges_batched semantics (selection_scorer.py:255-362), "sequential" = select_topn_ranges per
     row at token t0 + s (:124-249).  Returns (ranges [B,S,G,W,2] int32, O [B,S,G,h,Dv]) -- bit-identical to
     select_topn_ranges_batched / select_topn_ranges_rows followed by selection_attention_hip."""
