@@ -12,7 +12,8 @@
 //   3. dK, dV, KEY-BLOCK-major: one workgroup owns 64 keys of one (b,g) and keeps their dK/dV (64x64 fp32 each) in MFMA
 //      accumulators while it sweeps every query row that selected the block.  The rows are found by scanning the range
 //      lists (lane = row) and compacted in ascending t, so the summation order is fixed.  Rows are processed two at a
-//      time (2 x 6 heads = 12 of the 16 MFMA columns):  S = Q.K^T, dP = dO.V^T (16x16x32), then dV += P^T.dO and
+//      time in round 1 (2 x 6 heads = 12 of the 16 MFMA rows); round 2 lays the (row, head) slots end to end, every tile full:
+//      S = Q.K^T, dP = dO.V^T (16x16x32), then dV += P^T.dO and
 //      dK += dS^T.Q as 16x16x16 MFMAs whose A operand is taken straight from the S/dP accumulators (their row index,
 //      the (query,head) slot, is the contraction index) and whose B operand is read transposed from LDS.
 #include "nsa_common.hpp"
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int rho = lane & 15, q = lane >> 4;
     const int b = bg / P.G, g = bg % P.G;
-    const int h = P.h, RPT = 16 / h;  // query rows per column tile
+    const int h = P.h;
     const int key0 = 64 * j;
     const T *Kb = (const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg;
     const T *Vb = (const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg;
@@ -679,9 +680,12 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         pend = 0;
         __syncthreads();
 
-        // ---- process the hit rows, KB_NCT column tiles (= KB_NCT*RPT rows) per staging round.  The global loads of
+        // ---- process the hit rows, KB_NCT tiles of 16 (row, head) slots per staging round.  The global loads of
         // round r+1 (Q, dO rows, lse, delta) are issued into registers before the MFMAs of round r.
-        const int rows_per_round = KB_NCT * RPT;
+        // slots are laid end to end: slot = h * (row of the round) + head, so a round holds SLOTS / h rows and every 16-slot tile is
+        // full (two rows x 6 heads per tile left a quarter of the MFMA rows idle; a slot is one independent (row, head) pair, its tile is
+        // only the contraction group of the dV / dK products)
+        const int rows_per_round = SLOTS / h;
         u32x4 qa[NLD], da[NLD];
         float l2n = 0.f, dln = 0.f;
         unsigned long long mkn = 0ull;
@@ -689,11 +693,11 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
-                const int ct = slot >> 4, sl = slot & 15, qi = sl / h, hh = sl % h;
-                const int li = r0 + ct * RPT + qi;
+                const int qi = slot / h, hh = slot - qi * h;
+                const int li = r0 + qi;
                 qa[i] = (u32x4){0u, 0u, 0u, 0u};
                 da[i] = (u32x4){0u, 0u, 0u, 0u};
-                if (qi < RPT && li < nhit) {
+                if (qi < rows_per_round && li < nhit) {
                     const int64_t rrow = ((int64_t)b * P.S + s_t[li]) * P.G + g;
                     qa[i] = *(const u32x4 *)((const T *)P.Q + (rrow * h + hh) * (int64_t)BD + pc * 8);
                     da[i] = *(const u32x4 *)((const T *)P.dO + (rrow * h + hh) * (int64_t)BD + pc * 8);
@@ -703,9 +707,9 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
             dln = 0.f;
             mkn = 0ull;
             if (tid < SLOTS) {
-                const int ct = tid >> 4, sl = tid & 15, qi = sl / h, hh = sl % h;
-                const int li = r0 + ct * RPT + qi;
-                if (qi < RPT && li < nhit) {
+                const int qi = tid / h, hh = tid - qi * h;
+                const int li = r0 + qi;
+                if (qi < rows_per_round && li < nhit) {
                     const int64_t rrow = ((int64_t)b * P.S + s_t[li]) * P.G + g;
                     l2n = P.lse[rrow * h + hh] * LOG2E;
                     dln = delta[rrow * h + hh];
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
             }
             if (r0 + rows_per_round < nhit) fetch_round(r0 + rows_per_round);
             __syncthreads();
-            const int ntile = min(KB_NCT, (nhit - r0 + RPT - 1) / RPT);
+            const int ntile = min(KB_NCT, (min(nhit - r0, rows_per_round) * h + 15) >> 4);
             for (int ct = 0; ct < ntile; ++ct) {
                 const int sbase = 16 * ct;
                 f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
