@@ -681,3 +681,26 @@ def test_backward_properties_at_config5_size(nv):
     assert not g1[1][:, :, S:].any() and not g1[2][:, :, S:].any()  # keys beyond every range: never hit
     assert not g1[0][:, :63].any()  # rows without a token
     assert g1[1][:, :, :S].abs().amax(dim=(2, 3)).min().item() > 0 and g1[0][:, 64:].abs().amax(dim=(2, 3, 4)).min().item() > 0
+
+
+@pytest.mark.parametrize("S", [300, 1501, 4096])
+def test_flat_block_kernel_matches_four_tile_form(nv, orc, tune, S):
+    """h = 6: the block-form attention with the 8 rows of a wave on three full column tiles against the four-tile form and the oracle: a column
+    is one (row, head) pair either way, so the two forms differ by rounding only (different MFMA groupings of the same columns)"""
+    torch.manual_seed(S)
+    B, G, h, D = 2, 2, 6, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, 16, S)
+    out = {}
+    for flat in (0, 1):
+        tune("SEL_FLAT", flat)
+        out[flat] = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
+    torch.cuda.synchronize()
+    assert (out[0][0].float() - out[1][0].float()).abs().max().item() <= 2e-2
+    fin = torch.isfinite(out[0][1])
+    assert torch.equal(fin, torch.isfinite(out[1][1])) and (out[0][1][fin] - out[1][1][fin]).abs().max().item() <= 1e-3
+    want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
+    assert np.abs(out[1][0].float().cpu().numpy() - want).max() <= 1e-2

@@ -543,3 +543,27 @@ def test_g10_ranges_from_q_k_are_exact_where_the_score_gap_allows(nv, orc, S):
               f"{(1 - same_seq[~gated].mean()) if (~gated).any() else 0.0:.4f}")
         assert gated.mean() > 0.9  # the gate must not be vacuous
         assert same_seq[gated].all() and same_bat[gated].all(), tag
+
+
+@pytest.mark.parametrize("S,B", [(777, 2), (4096, 2), (16500, 1)])
+def test_flat_scorer_matches_four_tile_form(nv, tune, S, B):
+    """h = 6: the scorer with the 8 queries of a wave on three full column tiles (queries 2 and 5 straddle two tiles) against the four-tile
+    form -- the same logits, exponentials and stencil per (query, head); only the order of the six head terms of the straddling queries
+    differs (fp32 rounding)"""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S)
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, 2, 6, 64, device="cuda", generator=g).bfloat16()
+    Kc = torch.randn(B, 2, meta.S_cmp, 64, device="cuda", generator=g).bfloat16()
+    out = {}
+    for form in (0, 1):
+        tune("SCORES_FORM", form)
+        out[form] = nv.selection_scores(Q, Kc, meta, 0.125)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[1]).all()
+    assert (out[0] - out[1]).abs().max().item() <= 2e-6
+    # queries that do not straddle (0, 1, 3, 4, 6, 7 of every 8) sum their heads in the same order: bit-identical
+    keep = torch.tensor([t % 8 not in (2, 5) for t in range(S)], device="cuda")
+    assert torch.equal(out[0][:, keep], out[1][:, keep])
