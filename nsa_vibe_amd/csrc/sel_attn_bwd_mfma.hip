@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * IMG];  // the K/V block images alias the staging images (only read before the loop)
     __shared__ __attribute__((aligned(16))) float s_lse2[SLOTS], s_delta[SLOTS];
     __shared__ __attribute__((aligned(16))) unsigned long long s_mask[SLOTS];
+    __shared__ int s_tilefull[KB_NCT];  // every used slot of the tile covers all 64 keys of the block: the mask test is skipped
     __shared__ int s_t[512];
     __shared__ unsigned long long s_m[512];
     unsigned char *k_img = lds, *v_img = lds + 64 * BROWB;
@@ -732,6 +733,11 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
                 s_lse2[tid] = l2n;
                 s_delta[tid] = dln;
                 s_mask[tid] = mkn;
+                // slots past the last hit row carry zero Q / dO rows, lse2 = delta = 0: p = 1 there multiplies zeros -- they count as full
+                const int qi = tid / h;
+                const bool fullslot = mkn == ~0ull || !(qi < rows_per_round && r0 + qi < nhit);
+                const unsigned long long fb = __ballot(fullslot);  // waves 0 and 1: 64 slots = 4 tiles each
+                if (lane < 4) s_tilefull[4 * wave + lane] = ((fb >> (16 * lane)) & 0xffffull) == 0xffffull;
             }
             if (r0 + rows_per_round < nhit) fetch_round(r0 + rows_per_round);
             __syncthreads();
@@ -747,13 +753,24 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
                 // accumulator rows = slots sbase + 4q + r, column = key 16 wave + rho
                 const f32x4 l2 = *(const f32x4 *)(s_lse2 + sbase + 4 * q);
                 const f32x4 dl = *(const f32x4 *)(s_delta + sbase + 4 * q);
+                // dS carries no `scale` here: dK is multiplied once when it is written (MFMA and VALU issue add up: every VALU instruction
+                // of this loop is paid in full).  Most tiles are fully covered (whole selection blocks): no per-key mask test for them.
                 x4 pa, dsa;
+                if (uniform(s_tilefull[ct])) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool cov = (s_mask[sbase + 4 * q + r] >> (16 * wave + rho)) & 1ull;
-                    const float p = cov ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r])) : 0.f;
-                    pa[r] = Elt<T>::from_f(p);
-                    dsa[r] = Elt<T>::from_f(p * (dP[r] - dl[r]) * P.scale);
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r]));
+                        pa[r] = Elt<T>::from_f(p);
+                        dsa[r] = Elt<T>::from_f(p * (dP[r] - dl[r]));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool cov = (s_mask[sbase + 4 * q + r] >> (16 * wave + rho)) & 1ull;
+                        const float p = cov ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r])) : 0.f;
+                        pa[r] = Elt<T>::from_f(p);
+                        dsa[r] = Elt<T>::from_f(p * (dP[r] - dl[r]));
+                    }
                 }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
@@ -792,7 +809,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const
         if (key < P.S_kv) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                dKb[(int64_t)key * BD + 16 * n + rho] = dK[n][r];
+                dKb[(int64_t)key * BD + 16 * n + rho] = dK[n][r] * P.scale;
                 dVb[(int64_t)key * BD + 16 * n + rho] = dV[n][r];
             }
         }
