@@ -679,7 +679,7 @@ def main():
         if not args.no_extra and world == 1:
             extra = {}
             try:
-                for Bd, Sd in ((64, 16384), (64, 65536), (1, 65536)):
+                for Bd, Sd in ((64, 16384), (128, 16384), (256, 16384), (64, 65536), (1, 65536)):
                     d = decode_bench(nv, Bd, Sd, 30, device)
                     extra[f"decode_B{Bd}_S{Sd}"] = d
                     rl = decode_roofline(d, pmc_traffic(f"decode_B{Bd}_S{Sd}"))
