@@ -28,7 +28,9 @@ struct SelectParams {
 // scr: 128 ints of LDS private to the wave, or null.  With it the runs of the selected bitmap are extracted by all lanes at once (a lane
 // that starts / ends a run knows the run's index from the bits below it and drops the token bound into slot [index]); without it one
 // scalar loop walks the runs (about 30 dependent scalar instructions per run: 1.5 us of a decode step).
-template <int CAND>
+// SORT_ALL: keep the per-lane sorted copy also beyond 16 candidates per lane (the select kernel has the registers for it; the fused
+// kernels, at 1024 threads or 250 VGPRs, do not)
+template <int CAND, bool SORT_ALL = false>
 __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, const float *p, const int t, int &my_s, int &my_e,
                                                      int *scr = nullptr) {
     const int lane = lane_id();
@@ -122,7 +124,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
             const bool ok = key[c] > -INFINITY;  // forced / masked / NaN candidates never compete
             u[c] = ok ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0u;  // valid keys map to >= 0x00800000
         }
-        constexpr bool SORTED = CAND <= 16;  // beyond 1024 blocks the sorted copy would not fit the register budget: plain counting
+        constexpr bool SORTED = CAND <= 16 || SORT_ALL;  // beyond 1024 blocks the sorted copy does not fit the fused kernels' register budget
         unsigned w[CAND];  // per-lane descending copy (Batcher's odd-even merge sort, CAND a power of two)
 #pragma unroll
         for (int c = 0; c < CAND; ++c) w[c] = u[c];
@@ -281,7 +283,7 @@ template <int CAND>
 __device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out, int *scr = nullptr) {
     const int lane = lane_id();
     int my_s, my_e;
-    select_topn_row_regs<CAND>(P, p, t, my_s, my_e, scr);
+    select_topn_row_regs<CAND, (CAND <= 32)>(P, p, t, my_s, my_e, scr);
     if (lane < P.W) {
         out[2 * lane] = my_s;
         out[2 * lane + 1] = my_e;
