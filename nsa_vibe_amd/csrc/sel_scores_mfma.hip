@@ -109,7 +109,22 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     const int ntiles = (P.S_cmp + TILE_ROWS - 1) / TILE_ROWS;
     // staging: thread -> (row, piece) pairs
     u32x4 stg[LD_PER_THREAD];
+    // full tiles: one scalar base per tile + a lane-constant 32-bit offset (the per-lane 64-bit row arithmetic with its clamp was 16 VALU
+    // instructions per tile and wave in a kernel bound by instruction issue); only the last, padded tile clamps its rows
+    unsigned toff[LD_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+        const int p = tid + 256 * i;
+        toff[i] = (unsigned)((p / PIECES) * (int)P.css + (p % PIECES) * 8) * (unsigned)sizeof(T);
+    }
+    const bool small_stride = P.css * (int64_t)TILE_ROWS * (int64_t)sizeof(T) < ((int64_t)1 << 31);
     auto load_tile = [&](int tile) {
+        if (small_stride && (tile + 1) * TILE_ROWS <= P.S_cmp) {
+            const unsigned char *base = (const unsigned char *)(Kc + (int64_t)tile * TILE_ROWS * P.css);  // wave uniform
+#pragma unroll
+            for (int i = 0; i < LD_PER_THREAD; ++i) stg[i] = *(const u32x4 *)(base + toff[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
             const int p = tid + 256 * i;
@@ -236,6 +251,12 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     float rot_prev[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) rot_prev[n] = 0.f;
+    // output addressing: one scalar base per sequence + a 32-bit element offset per column tile (S G S_sel < 2^31 elements per sequence:
+    // checked by the host)
+    float *pg_b = P.p_grp + (int64_t)b * P.S * P.G * P.S_sel;
+    unsigned poff[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) poff[n] = (unsigned)((max(tq[n], 0) * P.G + g) * P.S_sel);
     if (tiles2 > 0) {
         load_tile(0);
         store_tile(0);
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
             for (int n = 0; n < NT; ++n) {
                 const bool first_head = FLAT ? ((16 * n + rho) % h) == 0 : (rho % h) == 0;
                 if (tq[n] >= 0 && first_head && j <= jlast)
-                    P.p_grp[(((int64_t)b * P.S + tq[n]) * P.G + g) * (int64_t)P.S_sel + j] = grps[n];
+                    pg_b[poff[n] + (unsigned)j] = grps[n];
             }
         }
         if (tile + 1 < tiles2) store_tile(buf ^ 1);
@@ -367,6 +388,7 @@ int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, i
                   "scores_mfma: Q/K_cmp must be 16-byte aligned with strides that are multiples of 8 elements");
     NSA_CHECK_ARG((int64_t)B * G <= 65535, "scores_mfma: B*G too large for one launch");
     NSA_CHECK_ARG(S_cmp >= 1, "scores_mfma: S_cmp must be >= 1");
+    NSA_CHECK_ARG((int64_t)S * G * S_sel < ((int64_t)1 << 31), "scores_mfma: S*G*S_sel must stay below 2^31 (32-bit output offsets per sequence)");
     // blocks the second sweep does not visit (causal skip, or selection blocks without any compressed row) are zero -- unless the caller
     // asked for causal_skip == 2: it then reads only entries with (j+1) l' <= t+1 (what both selectors do), all of which are written
     if (causal_skip != 2) NSA_HIP_TRY(hipMemsetAsync(p_grp, 0, sizeof(float) * (size_t)B * S * G * S_sel, st));
