@@ -113,10 +113,22 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
 
     // ---- (1) bitmaps cleared, ranges of the rows -> LDS (from the fused selector or the ranges tensor)
     for (int i = lane; i < 2 * tpw * NW + 2 * tpw; i += 64) fullw[i] = 0u;
-    for (int r = 0; r < ntok; ++r) {
-        const int64_t row = ((int64_t)b * P.S + tw0 + r) * P.G + g;
-        int s = 0, e = 0;
-        if (P.fuse_select) {
+    auto mark_blocks = [&](int r, int s, int e) {  // one (row, range) pair per lane -> the row's block bitmaps
+        if (e > s) {
+            const int ta = s >> 6, tb = (e - 1) >> 6;          // blocks touched
+            const int fa = (s + 63) >> 6, fb = (e >> 6) - 1;   // blocks covered completely: fa..fb
+            for (int w = ta >> 5; w <= (tb >> 5); ++w) {
+                const int base = 32 * w;
+                lds_or(&touchw[r * NW + w], span(max(ta, base) - base, min(tb, base + 31) - base));
+                const int flo = max(fa, base), fhi = min(fb, base + 31);
+                if (flo <= fhi) lds_or(&fullw[r * NW + w], span(flo - base, fhi - base));
+            }
+        }
+    };
+    if (P.fuse_select) {
+        for (int r = 0; r < ntok; ++r) {
+            const int64_t row = ((int64_t)b * P.S + tw0 + r) * P.G + g;
+            int s = 0, e = 0;
             const int t = SP.t_rows ? SP.t_rows[row] : SP.t0 + tw0 + r;
             const float *pg = SP.p_grp + row * (int64_t)SP.S_sel;
             switch (cand) {
@@ -130,34 +142,30 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
                 int32_t *out = SP.out + row * (int64_t)n * 2;
                 out[2 * lane] = s;
                 out[2 * lane + 1] = e;
+                s = min(max(s, 0), P.S_kv);
+                e = min(max(e, s), P.S_kv);
+                rg[2 * (r * n + lane)] = s;
+                rg[2 * (r * n + lane) + 1] = e;
             }
-        } else if (lane < n) {
-            const int32_t *in = P.ranges + (row * n + lane) * 2;
-            s = in[0];
-            e = in[1];
         }
-        if (lane < n) {
+        wave_lds_fence();
+        // ---- (2) block bitmaps: one (row, range) pair per lane
+        for (int p = lane; p < ntok * n; p += 64) mark_blocks(p / n, rg[2 * p], rg[2 * p + 1]);
+    } else {
+        // the ranges of ALL rows of the wave in one round of loads, one (row, range) pair per lane (a load per row, one row after the other,
+        // put 8 dependent memory round trips in front of every wave: the setup was 15 % of the kernel at S = 4096), and straight on into
+        // the bitmaps (the cleared words are visible: same wave, LDS operations complete in order)
+        wave_lds_fence();
+        for (int p = lane; p < ntok * n; p += 64) {
+            const int r = p / n, i = p - r * n;
+            const int64_t row = ((int64_t)b * P.S + tw0 + r) * P.G + g;
+            const int32_t *in = P.ranges + (row * n + i) * 2;
+            int s = in[0], e = in[1];
             s = min(max(s, 0), P.S_kv);
             e = min(max(e, s), P.S_kv);
-            rg[2 * (r * n + lane)] = s;
-            rg[2 * (r * n + lane) + 1] = e;
-        }
-    }
-    wave_lds_fence();
-
-    // ---- (2) block bitmaps: one (row, range) pair per lane
-    for (int p = lane; p < ntok * n; p += 64) {
-        const int r = p / n;
-        const int s = rg[2 * p], e = rg[2 * p + 1];
-        if (e > s) {
-            const int ta = s >> 6, tb = (e - 1) >> 6;          // blocks touched
-            const int fa = (s + 63) >> 6, fb = (e >> 6) - 1;   // blocks covered completely: fa..fb
-            for (int w = ta >> 5; w <= (tb >> 5); ++w) {
-                const int base = 32 * w;
-                lds_or(&touchw[r * NW + w], span(max(ta, base) - base, min(tb, base + 31) - base));
-                const int flo = max(fa, base), fhi = min(fb, base + 31);
-                if (flo <= fhi) lds_or(&fullw[r * NW + w], span(flo - base, fhi - base));
-            }
+            rg[2 * p] = s;
+            rg[2 * p + 1] = e;
+            mark_blocks(r, s, e);
         }
     }
     wave_lds_fence();
