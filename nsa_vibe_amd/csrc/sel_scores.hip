@@ -404,21 +404,24 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
     // CSC of a decode cache whose meta is older than its K_cmp lacks the newest rows, but those only reach the current and the previous
     // block, both forced: the ranges are the same (p_grp stays inside the kernel).
     const int j_pre = wave * 64 + lane;  // the block of this thread in the first round of phase 2b
-    int k0_pre = 0, k1_pre = 0, rr_pre[8];
-    float vv_pre[8];
+    int k0_pre = 0, k1_pre = 0, rr_pre[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float vv_pre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!P.stencil) {
         const int jj = min(j_pre, P.S_sel - 1);  // unconditional loads (clamped): see taps_pre
         k0_pre = P.csc_ptr[jj];
         k1_pre = P.csc_ptr[jj + 1];
     }
-    auto taps_pre = [&]() {  // second hop: issued behind the first K_cmp loads, so waiting for csc_ptr does not hold those back.  The
-                             // loads are unconditional (index clamped into the column, or to entry 0: S_cmp >= 1 means nnz >= 1) and
-                             // their values are not looked at before phase 2b
+    auto taps_pre = [&]() {  // second hop: issued behind the first K_cmp loads, so waiting for csc_ptr does not hold those back.  Inside a
+                             // non-empty column the loads are unconditional (index clamped into the column) and their values are not
+                             // looked at before phase 2b.  An EMPTY column loads nothing: the CSC of a cache whose meta dates from before
+                             // the first compressed token has no entries at all (null arrays) while S_cmp is already 1.
+        if (k1_pre > k0_pre) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int k = max(min(k0_pre + t, k1_pre - 1), 0);
-            rr_pre[t] = P.csc_rows[k];
-            vv_pre[t] = P.csc_vals[k];
+            for (int t = 0; t < 8; ++t) {
+                const int k = min(k0_pre + t, k1_pre - 1);
+                rr_pre[t] = P.csc_rows[k];
+                vv_pre[t] = P.csc_vals[k];
+            }
         }
     };
     // ---- phase 1: logits of 64 compressed rows per wave and step (MFMA rows), heads = columns

@@ -567,3 +567,31 @@ def test_flat_scorer_matches_four_tile_form(nv, tune, S, B):
     # queries that do not straddle (0, 1, 3, 4, 6, 7 of every 8) sum their heads in the same order: bit-identical
     keep = torch.tensor([t % 8 not in (2, 5) for t in range(S)], device="cuda")
     assert torch.equal(out[0][:, keep], out[1][:, keep])
+
+
+@pytest.mark.parametrize("geom", [(32, 16, 64), (16, 16, 32)])
+def test_fused_decode_with_a_meta_from_before_the_first_compressed_token(nv, tune, geom):
+    """a cache whose meta was built while S < l has an EMPTY Eq.9 map (no CSC entries at all) although K_cmp already holds its first token:
+    the fused decode kernel must not touch the (null) tap arrays -- both with the closed-form taps and when it reads the CSC (tuning switch,
+    and always for a geometry without the closed form) -- and selects what the current meta selects (only forced blocks exist this early)"""
+    import torch
+
+    l, d, l_sel = geom
+    t = l - 1 + d  # two compressed tokens exist, the meta dates from before the first one
+    S_now, S_old = t + 1, l - 4
+    meta_now, meta_old = nv.build_block_meta(S_now, l, d, l_sel, 16, 512), nv.build_block_meta(S_old, l, d, l_sel, 16, 512)
+    assert meta_old.S_cmp == 0 and meta_old.csc_rows.numel() == 0 and meta_now.S_cmp == 2
+    if meta_old.S_sel != meta_now.S_sel:
+        pytest.skip("the selection-block count changed in between: the reference rebuilds the meta then")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(l)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).bfloat16()  # noqa: E731
+    Q, Kc, K, V = mk(2, 1, 2, 4, 64), mk(2, 2, meta_now.S_cmp, 64), mk(2, 2, S_now, 64), mk(2, 2, S_now, 64)
+    outs = []
+    for stencil in (1, 0):
+        tune("DECODE_STENCIL", stencil)
+        outs.append(nv.selection_decode_step(Q, Kc, K, V, meta_old, 16, t))
+    outs.append(nv.selection_decode_step(Q, Kc, K, V, meta_now, 16, t))
+    torch.cuda.synchronize()
+    for O, r in outs[:2]:
+        assert torch.equal(r, outs[2][1]) and torch.equal(O, outs[2][0])
