@@ -1,0 +1,12 @@
+#!/bin/bash
+# The GPU suite under the non-default kernel forms (run on the GPU box): every A/B switch of nsa_hip_set_tuning keeps an older or alternative
+# form of a kernel alive, and only the defaults run in a plain `pytest -m gpu`.  Each set must pass like the defaults do.
+#   tools/run_alt_tunings.sh            (about a minute per set)
+set -e
+cd "$(dirname "$0")/.."
+run() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -1; }
+run NSA_HIP_SEL_FLAT=1 NSA_HIP_SEL_FUSE=1
+run NSA_HIP_SEL_FLAT=0 NSA_HIP_SCORES_FORM=0 NSA_HIP_DECODE_STENCIL=0 NSA_HIP_SEL_ROWSUM=0
+run NSA_HIP_SEL_ROWS=1 NSA_HIP_DECODE_UNFUSED=1 NSA_HIP_DECODE_WG=0
+run NSA_HIP_SEL_ROWS=0 NSA_HIP_ATTN_STAGE=0 NSA_HIP_BAND_STAGE=0 NSA_HIP_ATTN_MAP=0
+run NSA_HIP_SEL_BLOCKS=2 NSA_HIP_DECODE_UNFUSED=0 NSA_HIP_ATTN_MAP=1
