@@ -33,6 +33,7 @@ struct ScoresMfmaParams {
     float scale;
     int causal_skip;
     int d_stride;  // the compression stride d (tokens); l' = 4d
+    int big_out;   // S G S_sel >= 2^31 elements per sequence: 64-bit output offsets
 };
 
 template <typename T>
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
     float rot_prev[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) rot_prev[n] = 0.f;
-    // output addressing: one scalar base per sequence + a 32-bit element offset per column tile (S G S_sel < 2^31 elements per sequence:
-    // checked by the host)
+    // output addressing: one scalar base per sequence + a 32-bit element offset per column tile (the host sets big_out when S G S_sel
+    // reaches 2^31 elements per sequence: 64-bit offsets then)
     float *pg_b = P.p_grp + (int64_t)b * P.S * P.G * P.S_sel;
     unsigned poff[NT];
 #pragma unroll
@@ -347,7 +348,10 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
             for (int n = 0; n < NT; ++n) {
                 const bool first_head = FLAT ? ((16 * n + rho) % h) == 0 : (rho % h) == 0;
                 if (tq[n] >= 0 && first_head && j <= jlast)
-                    pg_b[poff[n] + (unsigned)j] = grps[n];
+                {
+                    if (P.big_out) P.p_grp[(((int64_t)b * P.S + tq[n]) * P.G + g) * (int64_t)P.S_sel + j] = grps[n];
+                    else pg_b[poff[n] + (unsigned)j] = grps[n];
+                }
             }
         }
         if (tile + 1 < tiles2) store_tile(buf ^ 1);
@@ -388,11 +392,12 @@ int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, i
                   "scores_mfma: Q/K_cmp must be 16-byte aligned with strides that are multiples of 8 elements");
     NSA_CHECK_ARG((int64_t)B * G <= 65535, "scores_mfma: B*G too large for one launch");
     NSA_CHECK_ARG(S_cmp >= 1, "scores_mfma: S_cmp must be >= 1");
-    NSA_CHECK_ARG((int64_t)S * G * S_sel < ((int64_t)1 << 31), "scores_mfma: S*G*S_sel must stay below 2^31 (32-bit output offsets per sequence)");
+
     // blocks the second sweep does not visit (causal skip, or selection blocks without any compressed row) are zero -- unless the caller
     // asked for causal_skip == 2: it then reads only entries with (j+1) l' <= t+1 (what both selectors do), all of which are written
     if (causal_skip != 2) NSA_HIP_TRY(hipMemsetAsync(p_grp, 0, sizeof(float) * (size_t)B * S * G * S_sel, st));
-    ScoresMfmaParams P{Q, Kc, p_grp, B, S, G, h, S_cmp, S_sel, csb, csg, css, scale, causal_skip, d_stride};
+    ScoresMfmaParams P{Q, Kc, p_grp, B, S, G, h, S_cmp, S_sel, csb, csg, css, scale, causal_skip, d_stride,
+                       (int64_t)S * G * S_sel < ((int64_t)1 << 31) ? 0 : 1};
     if (dtype == NSA_DT_BF16) return Dk == 64 ? launch_scores_t<__bf16, 64>(P, st) : launch_scores_t<__bf16, 128>(P, st);
     return Dk == 64 ? launch_scores_t<_Float16, 64>(P, st) : launch_scores_t<_Float16, 128>(P, st);
 }
