@@ -646,25 +646,32 @@ def main():
               "frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS, "gathered_bytes_per_launch": gathered,
               "note": "64-key K/V blocks really brought into LDS (the 8 rows of one wave share a block any of them selected) vs the "
                       "~34.5 TB/s aggregate L2 bandwidth of the guide"}
-        common = {"kernel": "sel_attn_blocks_mfma_kernel (block-sparse selection attention over the rows' ranges)", "kernel_ms": t_att,
+        common = {"kernel": "sel_attn_blocks_mfma_kernel (block-sparse selection attention over the rows' ranges; from 64k keys on as two key halves "
+                            "on different XCDs + the merge launch, both inside kernel_ms and traffic)", "kernel_ms": t_att,
                   "mean_selected_tokens_per_row": Lmean, "algorithmic_gather_bytes_per_launch": alg_bytes,
                   "algorithmic_gather_GBps": alg_bytes / (t_att * 1e-3) / 1e9, "traffic": traffic}
-        if traffic is not None and traffic > 0.1 * gathered:
-            # the launch is bound by what leaves the L2s: a (b,g)'s K/V (16 MiB at 64k) does not fit the 4 MiB of an XCD's L2, a third of
-            # the gathered bytes miss and travel over the fabric (Infinity Cache / HBM).  achieved = those bytes (PMC) / live kernel time.
+        hbm = None
+        if traffic is not None:
             ach = traffic / (t_att * 1e-3) / 1e9
-            out["roofline"] = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS,
-                                   frac_of_measured_stream_rate=ach / 6290.0,
-                                   note="achieved = HBM-side bytes of the launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per the MI355X guide, "
-                                        "profiles/r02/traffic_*.json, same shape) / HIP-event kernel time.  The ALGORITHMIC gather (sum_rows L_row*256 B, "
-                                        "SURVEY 8(d)) is re-read ~S*n*l'/S_kv times per K/V row and is served mostly by L2 (algorithmic_gather_GBps "
-                                        "exceeds every memory roof): what binds is the L2-miss traffic, at the rate a streaming copy reaches "
-                                        "(6.29 TB/s measured in the guide = frac_of_measured_stream_rate)",
-                                   l2=l2, mfma=mfma)
+            hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                   "frac_of_measured_stream_rate": ach / 6290.0, "traffic": traffic,
+                   "note": "HBM-side bytes of the attention launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per the MI355X guide, "
+                           "profiles/r02/traffic_*.json, same shape) / HIP-event time"}
+        # what binds: the larger of the two memory-side fractions.  With the plain walk the 64k launch ran at 94 % of the rate a streaming
+        # copy reaches (115.6 GB of L2 misses: a (b,g)'s K/V is 16 MiB against 4 MiB of L2 per XCD); the key-split form (two key halves on
+        # different XCDs) cut the misses to 45 GB, and the launch now sits nearer to the L2 / L1->LDS path (the gathered blocks) than to HBM.
+        if hbm is not None and hbm["frac_of_measured_stream_rate"] >= l2["frac"]:
+            out["roofline"] = dict(common, **{k: v for k, v in hbm.items() if k != "note"},
+                                   note=hbm["note"] + ".  The ALGORITHMIC gather (sum_rows L_row*256 B, SURVEY 8(d)) is re-read ~S*n*l'/S_kv times per "
+                                        "K/V row and is served mostly by L2 (algorithmic_gather_GBps exceeds every memory roof): what binds is the "
+                                        "L2-miss traffic, at the rate a streaming copy reaches (6.29 TB/s measured in the guide)", l2=l2, mfma=mfma)
         else:
             out["roofline"] = dict(common, **{k: v for k, v in l2.items() if k != "note"},
-                                   note="K/V of a (b,g) fits its XCD's L2: the gather is L2 resident (PMC HBM traffic = `traffic`, ~compulsory), the launch "
-                                        "is bound by instruction issue and the L1->LDS path; see DESIGN 4.1c", mfma=mfma)
+                                   note="bound by the gather through L2 and the L1->LDS path: `achieved` = the 64-key K/V blocks really brought into LDS "
+                                        "(the union over the 8 rows of a wave) / HIP-event time, `peak` = the ~34.5 TB/s aggregate of the guide; `traffic` = "
+                                        "HBM-side bytes per step (PMC): what still misses L2.  The ALGORITHMIC gather (sum_rows L_row*256 B, SURVEY 8(d)) "
+                                        "is above every memory roof (algorithmic_gather_GBps): rows of a wave share blocks and L2 serves the re-reads",
+                                   hbm=hbm, mfma=mfma)
         out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att, "select_and_attention_one_call": t_sa,
                             "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
                                     "so the stages can sum to slightly more.  The step is three launches: scores, select, attention"}

@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "DECODE_STOP"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, 1, -1, 0};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, 1, -1, -1, 0};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -131,9 +131,11 @@ int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes) {
 
 // ------------------------------------------------------------------------------ attention
 size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype) {
-    (void)n_ranges;
     if (!sel_attn_mfma_supported(dtype, h, Dk, Dv)) return 0;
-    return sel_attn_mfma_workspace((int64_t)B * S * G, h, Dv, nullptr);
+    const size_t split_kv = sel_attn_mfma_workspace((int64_t)B * S * G, h, Dv, nullptr);
+    // key-split form of the block kernel (long contexts, several sequences): sized for the prefill case S_kv = S
+    const size_t key_split = sel_attn_ksplit_workspace(dtype, h, Dk, Dv, S, S, n_ranges, (int64_t)B * S * G);
+    return split_kv > key_split ? split_kv : key_split;
 }
 
 }  // extern "C"
@@ -184,6 +186,9 @@ int nsa::sel_attn_fwd_impl(const void *Q, const void *K, const void *V, const in
             P.nsplit = ns;
             P.defer_combine = defer;
             if (ns_used && defer) *ns_used = ns;
+        } else if (ns == 1 && workspace && ((uintptr_t)workspace % 16 == 0)) {
+            P.ks_ws = workspace;  // the block kernel may split the keys of a pair over two XCD groups (partial records go here)
+            P.ks_bytes = workspace_bytes;
         }
         return launch_sel_attn_fwd_mfma(P, dtype, st);
     }

@@ -47,6 +47,7 @@ enum Tune {
     TUNE_SEL_FUSE,          // NSA_HIP_SEL_FUSE: nsa_sel_select_attn_fwd, 1 = the selector runs inside the attention launch, 0 = two launches
     TUNE_SCORES_FORM,       // NSA_HIP_SCORES_FORM: fused scorer with h = 6, 1 = 8 queries on 3 column tiles (no idle columns), 0 = on 4 tiles
     TUNE_SEL_FLAT,          // NSA_HIP_SEL_FLAT: block-form attention with h = 6, 1 = 8 rows on 3 column tiles (no idle columns), 0 = on 4 tiles, -1 = by context length
+    TUNE_SEL_KSPLIT,        // NSA_HIP_SEL_KSPLIT: block-form attention with the keys of a pair split over two XCD groups: -1 by shape, 0 never, 1 always
     TUNE_DECODE_STOP,       // NSA_HIP_DECODE_STOP: measurement aid, the fused decode kernel returns after phase N (1 logits, 2 scores, 3 top-n); 0 = run all
     TUNE_COUNT
 };

@@ -47,7 +47,12 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 // 2 rows (12 of 16 columns) per tile and four tiles.  MFMA and VALU issue do not overlap on a gfx950 SIMD (tools/ubench/issue_rates.hip), so
 // the idle quarter of every tile cost both its MFMAs and its softmax arithmetic.  Rows 2 and 5 straddle two tiles: every column keeps its own
 // running max / sum / output (a column is one (row, head) pair either way), only the ownership masks see the difference.
-template <typename T, int NT, bool RS, bool FLAT>
+// KSPLIT: two workgroups per row group, each walking one half of the 8-block (128 KiB) stripes of the keys, on different XCDs (the pair index
+// carries the half, pairs go round-robin over the XCDs).  At 64k a (b,g)'s K/V is 16 MiB against 4 MiB of L2 per XCD and the launch is bound by
+// L2-miss traffic: half the footprint per XCD cuts the misses by more than the partial records cost (profiles/r02/p_key_split.txt).  Each half
+// leaves (m, l) in fp32 and its normalised O in f16 (2^-11 relative: below the rounding of the output dtype) per (row, head); a second small
+// launch merges the two in fixed order.
+template <typename T, int NT, bool RS, bool FLAT, bool KSPLIT = false>
 __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     static_assert(!FLAT || NT == 3, "the flat layout is 3 tiles of 16 columns = 8 rows x 6 heads");
     using namespace blk;
@@ -71,6 +76,11 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     } else {
         bg = blockIdx.x / W4;
         tc = blockIdx.x % W4;
+    }
+    [[maybe_unused]] int ksp = 0;  // KSPLIT: the walk of this workgroup covers the even (0) / odd (1) key stripes; bg counts (pair, half)
+    if constexpr (KSPLIT) {
+        ksp = bg & 1;
+        bg >>= 1;
     }
     const int grp = 4 * tc + wave;
     if (grp >= ngrp || bg >= nbg) return;
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     unsigned u0 = 0u;
     for (int r = 0; r < ntok; ++r)
         if (lane < NW) u0 |= touchw[r * NW + lane];
+    if constexpr (KSPLIT) u0 &= ksp ? 0xFF00FF00u : 0x00FF00FFu;  // stripes of 8 blocks, alternating: both halves see the same causal shape
     unsigned long long nz0 = __ballot(u0 != 0u);
 
     const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
@@ -412,6 +423,22 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
         if (!rowbit(nn)) continue;
         const int64_t orow = (((int64_t)b * P.S + tw0 + col_row(nn)) * P.G + g) * h + col_head(nn);
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+        if constexpr (KSPLIT) {  // partial record of this half: ml[orow][half] = (m, l), po[orow][half][64] = O / l in f16
+            float *ml = (float *)P.part;
+            _Float16 *po = (_Float16 *)(ml + (int64_t)P.R * h * 4) + (orow * 2 + ksp) * 64;
+            if (q == 0) {
+                ml[(orow * 2 + ksp) * 2] = mrun[nn];
+                ml[(orow * 2 + ksp) * 2 + 1] = ltot;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = (_Float16)(o[nn][m][j] * inv);
+                *(f16x4 *)(po + 16 * m + 4 * q) = ov;
+            }
+            continue;
+        }
         T *Or = (T *)P.O + orow * D;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -424,7 +451,42 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     }
 }
 
+// merge of the two key halves: thread = (row * h + head, 8 output elements)
+template <typename T>
+__global__ __launch_bounds__(256) void sel_attn_ksplit_combine_kernel(const float *__restrict__ ml, const _Float16 *__restrict__ po, T *__restrict__ O,
+                                                                      float *__restrict__ lse, int64_t nrh) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int oct = threadIdx.x & 7;
+    if (i >= nrh) return;
+    const f32x4 r = *(const f32x4 *)(ml + i * 4);  // m0, l0, m1, l1
+    const float M = fmaxf(r[0], r[2]);
+    const float w0 = r[1] > 0.f ? r[1] * __builtin_amdgcn_exp2f(r[0] - M) : 0.f, w1 = r[3] > 0.f ? r[3] * __builtin_amdgcn_exp2f(r[2] - M) : 0.f;
+    const float L = w0 + w1, a0 = L > 0.f ? w0 / L : 0.f, a1 = L > 0.f ? w1 / L : 0.f;
+    const f16x8 p0 = *(const f16x8 *)(po + (i * 2) * 64 + 8 * oct), p1 = *(const f16x8 *)(po + (i * 2 + 1) * 64 + 8 * oct);
+    typedef typename MfmaT<T>::x8 x8;
+    x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = Elt<T>::from_f((float)p0[j] * a0 + (float)p1[j] * a1);
+    *(x8 *)(O + i * 64 + 8 * oct) = out;
+    if (lse && oct == 0) lse[i] = L > 0.f ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
+}
+
 // ---- host side ----------------------------------------------------------------------------
+// key-split form wanted for this shape?  TUNE_SEL_KSPLIT: -1 = when the launch is bound by L2-miss traffic (measured, merge launch included,
+// profiles/r02/p_key_split.txt: 0.78-0.83 x the time of the plain walk at 64k with B = 4 ... 16, 0.90-0.93 x with B = 1 ... 3, 0.94 x at 48k
+// with B = 4; 1.03 x at 40k, 1.09 x at 48k with B = 1, 1.12 x at 32k), 0 never, 1 always
+static bool ksplit_rule(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R) {
+    const int mode = tuning(TUNE_SEL_KSPLIT);
+    if (mode == 0 || S <= 0 || Dv != 64 || Dk != 64 || !(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16)) return false;
+    const int64_t nbg = R / S;
+    if (mode > 0) return true;
+    return (int64_t)S_kv >= (int64_t)4096 * n || ((int64_t)S_kv >= (int64_t)3072 * n && nbg >= 8);
+}
+size_t sel_attn_ksplit_workspace(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R) {
+    if (!ksplit_rule(dtype, h, Dk, Dv, S, S_kv, n, R)) return 0;
+    return (size_t)R * h * (4 * sizeof(float) + 2 * 64 * sizeof(_Float16));
+}
+
 // Column tiles per wave for a shape, 0 = not covered (the query-tile kernel takes it).  TUNE_SEL_BLOCKS: -1 auto, 0 off, N forces NT = N.
 int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int64_t kss, int64_t vss) {
     if (!(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) || Dk != 64 || Dv != 64 || h < 1 || h > 16) return 0;
@@ -445,20 +507,20 @@ int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n,
     return nt;
 }
 
-template <typename T, int NT, bool FLAT>
+template <typename T, int NT, bool FLAT, bool KSPLIT = false>
 static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
     SelAttnParams P = P0;
     const int tpt = 16 / P.h, tpw = FLAT ? 8 : NT * tpt;
     P.tpw = tpt;
     P.nw = ((P.S_kv + 63) / 64 + 31) / 32;
     P.nsplit = 1;
-    P.part = nullptr;
+    P.part = KSPLIT ? (float *)P0.ks_ws : nullptr;
     const int rg_ints = (2 * tpw * P.n + 3) & ~3;
     const int bm_ints = (2 * tpw * P.nw + 2 * tpw + 3) & ~3;
     P.wave_lds = 2 * blk::TILE_BYTES + 4 * (rg_ints + bm_ints);
     const size_t lds = 4 * (size_t)P.wave_lds;
     NSA_CHECK_ARG(lds <= 160 * 1024, "sel_attn_blocks: %zu B of LDS needed", lds);
-    const int64_t nbg = P.R / P.S;
+    const int64_t nbg = (P.R / P.S) * (KSPLIT ? 2 : 1);  // KSPLIT: (pair, key half) takes the place of the pair in the workgroup order
     const int64_t ngrp = (P.S + tpw - 1) / tpw;
     const int64_t W4 = (ngrp + 3) / 4;
     NSA_CHECK_ARG(nbg * W4 < (int64_t)1 << 31, "sel_attn_blocks: grid too large");
@@ -472,11 +534,18 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
         NSA_CHECK_ARG(c <= 16 && SP.W <= 64 && SP.W == P.n, "fused selection: S_sel <= 1024 and at most 64 ranges per row");
         cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : 16;
     }
-    void (*k)(SelAttnParams, SelectParams, int) =
-        tuning(TUNE_SEL_ROWSUM) ? sel_attn_blocks_mfma_kernel<T, NT, true, FLAT> : sel_attn_blocks_mfma_kernel<T, NT, false, FLAT>;
+    void (*k)(SelAttnParams, SelectParams, int) = tuning(TUNE_SEL_ROWSUM) ? sel_attn_blocks_mfma_kernel<T, NT, true, FLAT, KSPLIT>
+                                                                          : sel_attn_blocks_mfma_kernel<T, NT, false, FLAT, KSPLIT>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_blocks_mfma");
+    if constexpr (KSPLIT) {
+        const int64_t nrh = P.R * P.h;
+        const float *ml = (const float *)P.part;
+        hipLaunchKernelGGL(sel_attn_ksplit_combine_kernel<T>, dim3((unsigned)((nrh * 8 + 255) / 256)), dim3(256), 0, st, ml,
+                           (const _Float16 *)(ml + nrh * 4), (T *)P.O, P.lse, nrh);
+        NSA_LAUNCH_CHECK("sel_attn_ksplit_combine");
+    }
     return NSA_OK;
 }
 
@@ -487,6 +556,10 @@ int launch_sel_attn_blocks_mfma(const SelAttnParams &P, int dtype, int nt, hipSt
     // (+3 % at 16k, +4..10 % at 64k; same-box A/B, profiles/r02/k_flat_columns.txt).  TUNE_SEL_FLAT: -1 this rule, 0 never, 1 always.
     const int fmode = tuning(TUNE_SEL_FLAT);
     const bool flat = nt == 4 && P.h == 6 && (fmode > 0 || (fmode < 0 && (int64_t)P.S_kv <= (int64_t)384 * P.n));
+    // key halves on different XCDs (see the kernel): needs the caller's workspace, no fused selector, and the walk of a row group long enough
+    const size_t ks_need = (nt == 4 && !flat && !P.fuse_select) ? sel_attn_ksplit_workspace(dtype, P.h, P.Dk, P.Dv, P.S, P.S_kv, P.n, P.R) : 0;
+    if (ks_need > 0 && P.ks_ws && P.ks_bytes >= ks_need && (int64_t)P.R * P.h * 8 < ((int64_t)1 << 31))
+        return dtype == NSA_DT_BF16 ? launch_blocks_t<__bf16, 4, false, true>(P, st) : launch_blocks_t<_Float16, 4, false, true>(P, st);
     if (dtype == NSA_DT_BF16) {
         if (flat) return launch_blocks_t<__bf16, 3, true>(P, st);
         if (nt == 4) return launch_blocks_t<__bf16, 4, false>(P, st);

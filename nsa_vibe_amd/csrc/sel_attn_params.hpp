@@ -24,6 +24,8 @@ struct SelAttnParams {
     int fuse_select;    // the kernel first selects the row's ranges from its group scores (select = const SelectParams *, host)
     const void *select;
     int tpw, nw, wave_lds;  // query-tile form (sel_attn_rows_mfma.hip): rows per wave, 32-tile bitmap words per row, LDS bytes per wave
+    void *ks_ws;            // key-split form of the block kernel (sel_attn_blocks_mfma.hip): caller's workspace (16-byte aligned) or null
+    size_t ks_bytes;
 };
 
 struct SelAttnBwdParams {
@@ -89,6 +91,8 @@ int launch_sel_attn_fwd_mfma(const SelAttnParams &P, int dtype, hipStream_t st);
 size_t sel_attn_mfma_workspace(int64_t R, int h, int Dv, int *nsplit_out);
 // query-tile form: rows per wave for this shape, 0 = not covered (use the one-row-per-wave kernel)
 int sel_attn_rows_tpw(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int *nt);
+// key-split form of the block kernel: bytes of partial records it needs, 0 = not wanted for this shape (rule / tuning in sel_attn_blocks_mfma.hip)
+size_t sel_attn_ksplit_workspace(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R);
 int launch_sel_attn_rows_mfma(const SelAttnParams &P, int dtype, int tpw, int nt, hipStream_t st);
 // block form (64-key blocks, NT column tiles of 16/h rows per wave): column tiles per wave for this shape, 0 = not covered
 int sel_attn_blocks_nt(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R, int64_t kss, int64_t vss);

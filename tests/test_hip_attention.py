@@ -704,3 +704,33 @@ def test_flat_block_kernel_matches_four_tile_form(nv, orc, tune, S):
     assert torch.equal(fin, torch.isfinite(out[1][1])) and (out[0][1][fin] - out[1][1][fin]).abs().max().item() <= 1e-3
     want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
     assert np.abs(out[1][0].float().cpu().numpy() - want).max() <= 1e-2
+
+
+@pytest.mark.parametrize("B,S,G", [(2, 4096, 2), (1, 1501, 2), (3, 700, 1), (1, 300, 4)])
+def test_key_split_block_kernel_matches_plain_walk(nv, orc, tune, B, S, G):
+    """the block form with the keys of a pair split over two workgroup sets (even / odd 8-block stripes, partial (m, l, O / l) records in f16,
+    merged by a second launch) against the plain walk and the oracle, output and log-sum-exp; forced on by the tuning switch (by itself it
+    only applies to long contexts)"""
+    torch.manual_seed(S + B)
+    h, D = 6, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, 16, S)
+    rg[:, 5] = 0  # a row without any key
+    tune("SEL_FLAT", 0)
+    out = {}
+    for ks in (0, 1):
+        tune("SEL_KSPLIT", ks)
+        out[ks] = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
+    torch.cuda.synchronize()
+    assert (out[0][0].float() - out[1][0].float()).abs().max().item() <= 1.6e-2  # one bf16 ulp at |O| < 4
+    fin = torch.isfinite(out[0][1])
+    assert torch.equal(fin, torch.isfinite(out[1][1])) and (out[0][1][fin] - out[1][1][fin]).abs().max().item() <= 1e-3
+    assert not out[1][0][:, 5].any()
+    want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
+    assert np.abs(out[1][0].float().cpu().numpy() - want).max() <= 1e-2
+    # run to run: bit-identical (the halves are merged in a fixed order)
+    again = nv.selection_attention_hip(Q, K, V, rg)
+    assert torch.equal(again, out[1][0])
