@@ -11,7 +11,8 @@ rl = d["roofline"]
 print("roofline:", {k: r(v) for k, v in rl.items() if not isinstance(v, (dict, str)) or k in ("bound", "unit", "kernel")})
 for sub in ("l2", "mfma"):
     if sub in rl:
-        print("  ", sub, {k: r(v) for k, v in rl[sub].items() if k != "note"})
+        if isinstance(rl.get(sub), dict):
+            print("  ", sub, {k: r(v) for k, v in rl[sub].items() if k != "note"})
 print("stages_ms:", {k: r(v) for k, v in d.get("stages_ms", {}).items() if k != "note"})
 print("roofline_scores:", {k: r(v) for k, v in d.get("roofline_scores", {}).items() if k != "note"})
 print("decode_roofline:", {k: r(v) for k, v in d.get("decode_roofline", {}).items() if k not in ("workload", "formula")})
