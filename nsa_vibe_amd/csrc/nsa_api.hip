@@ -570,7 +570,9 @@ int nsa_sel_select_attn_fwd(const float *p_grp, int t0, const int32_t *t_rows, i
     // kernel held to 2 waves per SIMD by its 253 VGPRs: its scalar chains run at latency and it adds 36 / 120 / 424 us at 4k x 8 / 16k x 2 /
     // 64k x 1, where the select kernel on its own (a row per wave, 6+ waves per SIMD) takes 28 / 57 / 243 us (profiles/r02
     // i_selector_share.txt): two launches are the default.
-    const bool fuse = tuning(TUNE_SEL_FUSE) > 0;
+    // (never fused where the attention would split the keys over two XCD groups: that form takes its ranges from memory, and both ways of
+    // calling must give the same bits)
+    const bool fuse = tuning(TUNE_SEL_FUSE) > 0 && sel_attn_ksplit_workspace(dtype, h, Dk, Dv, S, S_kv, out_width, R) == 0;
     if (!fast_ok || !fuse) {  // two launches
         if (int rc = nsa_select_topn_ranges(p_grp, R, S, G, t0, t_rows, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, ranges_out,
                                             out_width, stream))
