@@ -88,10 +88,13 @@ NSA_API int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes);
  *          a row with no allowed token yields zeros (attention_kernels.py:734-749,769-771).
  *   lse    [B,S,G,h] fp32, nullable: log-sum-exp of the scaled logits (needed by the backward).
  *   scale  softmax scale; pass <=0 for the default Dk^-1/2.
- *   variant 0 = auto, 1 = generic VALU kernel, 2 = MFMA kernels (bf16/f16, Dk=Dv in {64,128}, h<=16): with many rows the query-tile
- *           form (16/h consecutive rows of one (b,g) per wave share each selected K/V tile), with few rows (decode) one row per
+ *   variant 0 = auto, 1 = generic VALU kernel, 2 = MFMA kernels (bf16/f16, Dk=Dv in {64,128}, h<=16): with many rows the block form
+ *           (8 consecutive rows of one (b,g) per wave walk the union of their 64-key blocks; from 64k keys on as two key halves on
+ *           different XCDs plus a merge launch) or the query-tile form, with few rows (decode) one workgroup per row or one row per
  *           wave with its tiles split over several waves.
- *   workspace: nsa_sel_attn_fwd_workspace() bytes (may be 0); used when few rows are split over KV.
+ *   workspace: nsa_sel_attn_fwd_workspace() bytes, 16-byte aligned (may be 0).  Holds the partial records when few rows are split
+ *           over KV and when a long context is split into key halves (272 B per (row, head): sized for S_kv = S); with a smaller or
+ *           no workspace the call falls back to the forms that need none.
  * ------------------------------------------------------------------------------------- */
 NSA_API size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype);
 NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O,
