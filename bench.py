@@ -404,6 +404,7 @@ def train_mode(nv, args, dist, world, rank, device):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks = rank_report(dist, world, elapsed, args.steps, device)
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -415,7 +416,8 @@ def train_mode(nv, args, dist, world, rank, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"one m7c_125m NSAAttention layer, forward+backward+SGD step, S={S}, B={B} per GPU, DDP "
                                    f"(gradient all-reduce of {sum(p.numel() for p in layer.parameters())} bf16 parameters per step)",
-                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world} (DistributedDataParallel over RCCL)"}}))
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world} (DistributedDataParallel over RCCL)"},
+            "ranks": ranks}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -464,6 +466,7 @@ def train_model_mode(nv, args, dist, world, rank, device):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks = rank_report(dist, world, elapsed, args.steps, device)
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -477,11 +480,31 @@ def train_model_mode(nv, args, dist, world, rank, device):
             "config": {"workload": f"m7c_125m TinyLM ({args.layers} NSA blocks, dim 768, vocab {V}, {n_par / 1e6:.1f} M parameters): forward + "
                                    f"cross-entropy + backward + clip + fused AdamW, S={S}, B={B} per GPU, random tokens and weights",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world} (DistributedDataParallel over RCCL)"},
-            "loss_after_warmup": first, "loss_last": float(loss_box[0]),
+            "ranks": ranks, "loss_after_warmup": first, "loss_last": float(loss_box[0]),
             "peak_mem_GiB": torch.cuda.max_memory_allocated(device) / 2 ** 30}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rank_report(dist, world, elapsed_local, steps, device):
+    """what lets the driver check a multi-rank line against itself: every rank contributes a 1 to an all-reduce over the measurement's
+    own process group (ranks_seen must equal --gpus: asserted), and the per-rank step times are reduced to their min / max (the line's
+    ms_per_step is the max).  Pattern: scripts/train_showcase.py:425-437, 718-723 (rank / world bookkeeping of the reference's trainer)."""
+    ms = elapsed_local / steps * 1e3
+    if dist is None:
+        return {"ranks_seen": 1, "ms_per_step_rank_min": ms, "ms_per_step_rank_max": ms, "backend": "none (single process)", "rccl": False}
+    one = torch.ones(1, device=device, dtype=torch.float64)
+    dist.all_reduce(one)
+    lo = torch.tensor([ms], device=device, dtype=torch.float64)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    seen = int(round(one.item()))
+    assert seen == world, f"all-reduce saw {seen} rank(s), the launcher promised {world}"
+    backend = dist.get_backend()
+    return {"ranks_seen": seen, "ms_per_step_rank_min": float(lo.item()), "ms_per_step_rank_max": float(hi.item()), "backend": backend,
+            "rccl": backend == "nccl"}
 
 
 def launch_ranks(args, argv):
@@ -526,19 +549,18 @@ def dry_main(args, world, rank):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ranks = rank_report(dist if world > 1 else None, world, elapsed, args.steps, torch.device("cpu"))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        seen = torch.tensor([1.0])
-        dist.all_reduce(seen)
-        assert int(seen.item()) == world
     if rank == 0:
         print(json.dumps({"metric": "dry_run_plumbing_only", "value": world * args.batch * args.seq / max(elapsed / args.steps, 1e-9), "unit": "tok/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "dry run (CPU, no kernels): launcher / rendezvous / timing plumbing only",
-                                     "global_batch": world * args.batch, "parallelism": f"{world} rank(s), backend {args.backend}"}}))
+                                     "global_batch": world * args.batch, "parallelism": f"{world} rank(s), backend {args.backend}"},
+                          "ranks": ranks}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -615,6 +637,7 @@ def main():
         hot_path(nv, meta, Q, Kc, K, V, S)
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks = rank_report(dist, world, elapsed, args.steps, device)
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -631,6 +654,7 @@ def main():
                                f"S={S}, B={B} per GPU (K/V {kv_mib:.0f} MiB resident in HBM), G={G} h={H} d_k=d_v={D}, l={L_CMP} d={D_CMP} "
                                f"l'={L_SEL} n={N_SEL}",
                    "global_batch": world * B, "seq_len": S, "parallelism": f"batch x group shard over {world} GPU(s), no collective"},
+        "ranks": ranks,
     }
     if rank == 0:
         t_sc, t_sel, t_att, t_sa, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))

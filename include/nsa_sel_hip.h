@@ -93,7 +93,7 @@ NSA_API int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes);
  *           different XCDs plus a merge launch) or the query-tile form, with few rows (decode) one workgroup per row or one row per
  *           wave with its tiles split over several waves.
  *   workspace: nsa_sel_attn_fwd_workspace() bytes, 16-byte aligned (may be 0).  Holds the partial records when few rows are split
- *           over KV and when a long context is split into key halves (272 B per (row, head): sized for S_kv = S); with a smaller or
+ *           over KV and when a long context is split into key halves (288 B per (row, head): sized for S_kv = S); with a smaller or
  *           no workspace the call falls back to the forms that need none.
  * ------------------------------------------------------------------------------------- */
 NSA_API size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype);

@@ -44,7 +44,11 @@ static void tune_init() {
         char name[64];
         snprintf(name, sizeof(name), "NSA_HIP_%s", g_tune_names[i]);
         const char *e = getenv(name);
-        g_tune[i].store(e ? atoi(e) : g_tune_defaults[i], std::memory_order_relaxed);
+        int v = e ? atoi(e) : g_tune_defaults[i];
+#ifndef NSA_DEC_TS
+        if (i == TUNE_DECODE_STOP) v = 0;  // TIMELINE build only (see nsa_hip_set_tuning)
+#endif
+        g_tune[i].store(v, std::memory_order_relaxed);
     }
 }
 
@@ -100,6 +104,10 @@ const char *nsa_hip_last_error(void) { return g_err; }
 int nsa_hip_set_tuning(const char *name, int value) {
     const int i = tune_index(name);
     NSA_CHECK_ARG(i >= 0, "unknown tuning switch '%s'", name ? name : "(null)");
+#ifndef NSA_DEC_TS
+    // the phase stops of the fused decode kernel leave O and the ranges unwritten: they exist in the TIMELINE build only
+    NSA_CHECK_ARG(i != TUNE_DECODE_STOP || value == 0, "DECODE_STOP is a measurement aid of the TIMELINE build (make TIMELINE=1)");
+#endif
     std::call_once(g_tune_once, tune_init);
     g_tune[i].store(value, std::memory_order_relaxed);
     return NSA_OK;
@@ -175,7 +183,7 @@ int nsa::sel_attn_fwd_impl(const void *Q, const void *K, const void *V, const in
                          ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0);
     if (variant == 2) NSA_CHECK_ARG(fast_ok, "sel_attn_fwd: MFMA variant requested but shape/dtype/alignment unsupported");
     NSA_CHECK_ARG(variant >= 0 && variant <= 2, "sel_attn_fwd: unknown variant %d", variant);
-    if (variant == 0 && S == 1 && !lse && sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_ranges, kss, vss, Q, K, V) &&
+    if (variant == 0 && S == 1 && !lse && sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_ranges, ksb, ksg, kss, vsb, vsg, vss, Q, K, V) &&
         (int64_t)S_kv * 128 < ((int64_t)1 << 31))  // decode: one workgroup per row, partials merged through LDS, no combine launch
         return launch_sel_attn_decode_wg(Q, K, V, ranges, O, R, G, h, S_kv, n_ranges, ksb, ksg, kss, vsb, vsg, vss, dtype, P.scale, st);
     if (variant == 2 || (variant == 0 && fast_ok)) {
@@ -622,7 +630,7 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
     float *p_grp = (float *)(w + a);
     int rc;
     const float sc = scale > 0.f ? scale : 1.0f / sqrtf((float)Dk);
-    const bool wg_attn = sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, kss, vss, Q, K, V) && S_kv >= 1 &&
+    const bool wg_attn = sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, ksb, ksg, kss, vsb, vsg, vss, Q, K, V) && S_kv >= 1 &&
                          (int64_t)S_kv * 128 < ((int64_t)1 << 31);
     const int stencil = (l == 2 * d && l_sel == 4 * d) ? 1 : 0;  // Eq.9 in closed form (the fused kernel then reads no CSC arrays)
     if (decode_score_select_supported(dtype, h, Dk, S_cmp, S_sel, kcb, kcg, kcs, Q, K_cmp, (int64_t)B * G)) {

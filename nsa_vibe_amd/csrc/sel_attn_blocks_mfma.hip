@@ -50,7 +50,8 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 // KSPLIT: two workgroups per row group, each walking one half of the 8-block (128 KiB) stripes of the keys, on different XCDs (the pair index
 // carries the half, pairs go round-robin over the XCDs).  At 64k a (b,g)'s K/V is 16 MiB against 4 MiB of L2 per XCD and the launch is bound by
 // L2-miss traffic: half the footprint per XCD cuts the misses by more than the partial records cost (profiles/r02/p_key_split.txt).  Each half
-// leaves (m, l) in fp32 and its normalised O in f16 (2^-11 relative: below the rounding of the output dtype) per (row, head); a second small
+// leaves (m, l, s) in fp32 and its normalised O / s in f16 (2^-11 relative: below the rounding of the output dtype; s = 1 unless the half's output
+// leaves the f16 range, then a power of two) per (row, head); a second small
 // launch merges the two in fixed order.
 template <typename T, int NT, bool RS, bool FLAT, bool KSPLIT = false>
 __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
@@ -423,18 +424,30 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
         if (!rowbit(nn)) continue;
         const int64_t orow = (((int64_t)b * P.S + tw0 + col_row(nn)) * P.G + g) * h + col_head(nn);
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-        if constexpr (KSPLIT) {  // partial record of this half: ml[orow][half] = (m, l), po[orow][half][64] = O / l in f16
-            float *ml = (float *)P.part;
-            _Float16 *po = (_Float16 *)(ml + (int64_t)P.R * h * 4) + (orow * 2 + ksp) * 64;
-            if (q == 0) {
-                ml[(orow * 2 + ksp) * 2] = mrun[nn];
-                ml[(orow * 2 + ksp) * 2 + 1] = ltot;
+        if constexpr (KSPLIT) {  // partial record of this half: ml[orow][half] = (m, l, s, -), po[orow][half][64] = O / (l s) in f16
+            // s = 1 unless the half's output leaves the f16 range (bf16 inputs with |V| > 32768): then the power of two that brings its
+            // largest element back below 2^15 -- the merge multiplies it back in, so the record never overflows where the plain walk is finite
+            float amax = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(o[nn][m][j] * inv));
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            float sc = 1.f, isc = 1.f;
+            if (amax > 32768.f && amax < INFINITY) {
+                const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127 - 14;  // amax / 2^e < 2^15
+                sc = __uint_as_float((unsigned)(e + 127) << 23);
+                isc = __uint_as_float((unsigned)(127 - e) << 23);
             }
+            float *ml = (float *)P.part;
+            _Float16 *po = (_Float16 *)(ml + (int64_t)P.R * h * 8) + (orow * 2 + ksp) * 64;
+            if (q == 0) *(f32x4 *)(ml + (orow * 2 + ksp) * 4) = (f32x4){mrun[nn], ltot, sc, 0.f};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f16x4 ov;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (_Float16)(o[nn][m][j] * inv);
+                for (int j = 0; j < 4; ++j) ov[j] = (_Float16)(o[nn][m][j] * inv * isc);
                 *(f16x4 *)(po + 16 * m + 4 * q) = ov;
             }
             continue;
@@ -458,10 +471,12 @@ __global__ __launch_bounds__(256) void sel_attn_ksplit_combine_kernel(const floa
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int oct = threadIdx.x & 7;
     if (i >= nrh) return;
-    const f32x4 r = *(const f32x4 *)(ml + i * 4);  // m0, l0, m1, l1
-    const float M = fmaxf(r[0], r[2]);
-    const float w0 = r[1] > 0.f ? r[1] * __builtin_amdgcn_exp2f(r[0] - M) : 0.f, w1 = r[3] > 0.f ? r[3] * __builtin_amdgcn_exp2f(r[2] - M) : 0.f;
-    const float L = w0 + w1, a0 = L > 0.f ? w0 / L : 0.f, a1 = L > 0.f ? w1 / L : 0.f;
+    const f32x4 r0 = *(const f32x4 *)(ml + i * 8), r1 = *(const f32x4 *)(ml + i * 8 + 4);  // (m, l, s, -) of either half
+    const float M = fmaxf(r0[0], r1[0]);
+    const float w0 = r0[1] > 0.f ? r0[1] * __builtin_amdgcn_exp2f(r0[0] - M) : 0.f, w1 = r1[1] > 0.f ? r1[1] * __builtin_amdgcn_exp2f(r1[0] - M) : 0.f;
+    const float L = w0 + w1;
+    // (s = 1 in every ordinary record: x * 1.0f is exact, the result is that of the unscaled merge bit for bit)
+    const float a0 = L > 0.f ? (w0 / L) * r0[2] : 0.f, a1 = L > 0.f ? (w1 / L) * r1[2] : 0.f;
     const f16x8 p0 = *(const f16x8 *)(po + (i * 2) * 64 + 8 * oct), p1 = *(const f16x8 *)(po + (i * 2 + 1) * 64 + 8 * oct);
     typedef typename MfmaT<T>::x8 x8;
     x8 out;
@@ -480,11 +495,14 @@ static bool ksplit_rule(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n
     if (mode == 0 || S <= 0 || Dv != 64 || Dk != 64 || !(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16)) return false;
     const int64_t nbg = R / S;
     if (mode > 0) return true;
-    return (int64_t)S_kv >= (int64_t)4096 * n || ((int64_t)S_kv >= (int64_t)3072 * n && nbg >= 8);
+    // keyed on the K/V footprint of a (b,g) pair against the 4 MiB of L2 per XCD (>= 16 MiB, or >= 12 MiB with at least 8 pairs), not on the
+    // number of range slots: a caller with a few wide ranges sees the same cache behaviour as the selector's 16 blocks
+    (void)n;
+    return S_kv >= 65536 || (S_kv >= 49152 && nbg >= 8);
 }
 size_t sel_attn_ksplit_workspace(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R) {
     if (!ksplit_rule(dtype, h, Dk, Dv, S, S_kv, n, R)) return 0;
-    return (size_t)R * h * (4 * sizeof(float) + 2 * 64 * sizeof(_Float16));
+    return (size_t)R * h * (8 * sizeof(float) + 2 * 64 * sizeof(_Float16));
 }
 
 // Column tiles per wave for a shape, 0 = not covered (the query-tile kernel takes it).  TUNE_SEL_BLOCKS: -1 auto, 0 off, N forces NT = N.
@@ -543,7 +561,7 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
         const int64_t nrh = P.R * P.h;
         const float *ml = (const float *)P.part;
         hipLaunchKernelGGL(sel_attn_ksplit_combine_kernel<T>, dim3((unsigned)((nrh * 8 + 255) / 256)), dim3(256), 0, st, ml,
-                           (const _Float16 *)(ml + nrh * 4), (T *)P.O, P.lse, nrh);
+                           (const _Float16 *)(ml + nrh * 8), (T *)P.O, P.lse, nrh);
         NSA_LAUNCH_CHECK("sel_attn_ksplit_combine");
     }
     return NSA_OK;

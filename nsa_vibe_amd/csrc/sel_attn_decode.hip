@@ -18,10 +18,12 @@ __global__ __launch_bounds__(1024) void sel_attn_decode_wg_kernel(DecAttnArgs A,
     decode_attend_row<T>(A, row, rs, re, dlds);
 }
 
-bool sel_attn_decode_wg_supported(int dtype, int h, int Dk, int Dv, int n, int64_t kss, int64_t vss, const void *Q, const void *K, const void *V) {
+bool sel_attn_decode_wg_supported(int dtype, int h, int Dk, int Dv, int n, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg,
+                                  int64_t vss, const void *Q, const void *K, const void *V) {
     if (tuning(TUNE_DECODE_WG) == 0) return false;
+    // 16-byte global loads and LDS-DMA pieces at K + b ksb + g ksg (+ row kss): every stride a multiple of 8 elements
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16 && n >= 1 && n <= 64 && vss == 64 &&
-           kss % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0);
+           kss % 8 == 0 && ksb % 8 == 0 && ksg % 8 == 0 && vsb % 8 == 0 && vsg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0);
 }
 
 int launch_sel_attn_decode_wg(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, int64_t R, int G, int h, int S_kv, int n,

@@ -81,7 +81,8 @@ int launch_band_attn_fwd_generic(const BandAttnParams &P, int dtype, hipStream_t
 int launch_sel_attn_fwd_generic(const SelAttnParams &P, int dtype, hipStream_t st);
 int launch_sel_attn_bwd_generic(const SelAttnBwdParams &P, int dtype, hipStream_t st);
 // decode form (S = 1): one 1024-thread workgroup per row, partials merged through LDS (sel_attn_decode.hpp)
-bool sel_attn_decode_wg_supported(int dtype, int h, int Dk, int Dv, int n, int64_t kss, int64_t vss, const void *Q, const void *K, const void *V);
+bool sel_attn_decode_wg_supported(int dtype, int h, int Dk, int Dv, int n, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg,
+                                  int64_t vss, const void *Q, const void *K, const void *V);
 int launch_sel_attn_decode_wg(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O, int64_t R, int G, int h, int S_kv, int n,
                               int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, hipStream_t st);
 int launch_sel_head_causal(const SelAttnParams &P, int dtype, hipStream_t st);  // parity mode of _sdpa_over_ranges

@@ -491,7 +491,9 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
             do_chunk(chunk, a);
         }
     }
-    if (stop == 1) return;  // measurement aid (TUNE_DECODE_STOP): every thread leaves together
+#ifdef NSA_DEC_TS
+    if (stop == 1) return;  // measurement aid of the TIMELINE build (TUNE_DECODE_STOP): every thread leaves together
+#endif
     DEC_TS(1);
     __syncthreads();
     DEC_TS(2);
@@ -600,7 +602,9 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
         }
         pg[j] = grp;
     }
+#ifdef NSA_DEC_TS
     if (stop == 2) return;
+#endif
     DEC_TS(4);
     __syncthreads();
     DEC_TS(5);
@@ -625,7 +629,9 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
     // ---- phase 4: selection attention of the row over the ranges just chosen (same workgroup: the 16 waves take the 64-key chunks,
     // partials merged through LDS -- sel_attn_decode.hpp).  The logits / scores in LDS are dead by now: their space holds the V tiles.
     if constexpr (ATTEND) {
+#ifdef NSA_DEC_TS
         if (stop == 3) return;
+#endif
         __syncthreads();
         DEC_TS(7);
         if constexpr (KSTEPS == 2) decode_attend_row<T, true>(AT, row, rs, re, (unsigned char *)dsm, qf);

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
             float grps[NT];
 #define NSA_HS1 "s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define NSA_HSA(K) "v_add_f32_dpp %0, %1, %0 row_shl:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define NSA_HSB(K) "v_add_f32_dpp %0, %1, %2 row_shl:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define NSA_HSB(K) "s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shl:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
             if constexpr (FLAT) {
                 // columns 16 n + rho = 6 query + head.  Query starts: tile 0 lanes 0, 6, 12 (12: heads 0-3 here, 4-5 = lanes 0-1 of tile 1);
                 // tile 1 lanes 2, 8, 14 (14: heads 0-1 here, 2-5 = lanes 0-3 of tile 2); tile 2 lanes 4, 10.

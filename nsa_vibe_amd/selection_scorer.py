@@ -38,7 +38,10 @@ def workspace(dev: torch.device, nbytes: int, tag: str = "ws") -> Optional[torch
         return None
     key = (tag, dev.index, torch.cuda.current_stream(dev).cuda_stream)  # per stream: two streams never share scratch
     buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
+    # grown on demand; given back when a much smaller shape follows a big one (the key-split records of a 64k prefill are gigabytes)
+    if buf is None or buf.numel() < nbytes or buf.numel() > max(4 * nbytes, 256 << 20):
+        _WS.pop(key, None)
+        buf = None
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
         _WS[key] = buf
     return buf

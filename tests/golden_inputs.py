@@ -96,3 +96,45 @@ def g11_inputs(ci, S, G, h, D, S_cmp):
     r = _rng(11, ci)
     B = 2 if S <= 512 else 1
     return (randn(r, B, S, G, h, D), randn(r, B, G, S_cmp, D), randn(r, B, G, S, D), randn(r, B, G, S, D))
+
+
+# g19: the reference NSAAttention module at the m7c_125m head geometry (oracle/make_m7c_module_goldens.py).  Weights and inputs are
+# regenerated from PCG64 streams on both sides (a 768-wide state dict is 7 MB: too big to commit) and are bf16-representable, so the
+# fp32 reference and a bf16 module see identical parameters and activations at the layer input.
+G19_CFG = dict(dim=768, n_heads=12, n_kv_groups=2, d_k=64, d_v=64, l=32, d=16, l_sel=64, n_sel=16, w=512)
+G19_S_PRE, G19_N_DEC, G19_B = 4096, 2200, 1
+
+
+def _bf16_round(a):
+    """fp32 array rounded to the nearest bf16 value (ties to even), still stored as fp32"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def g19_state(names_shapes):
+    """names_shapes: [(state-dict key, shape)] in the reference module's own order -> {key: fp32 array (bf16-representable)}"""
+    out = {}
+    for i, (name, shape) in enumerate(names_shapes):
+        shape = tuple(int(x) for x in shape)
+        r = _rng(19, i)
+        if len(shape) == 2:
+            w = randn(r, *shape) / np.float32(np.sqrt(shape[1]))
+        else:
+            w = randn(r, *shape) * np.float32(0.02)
+        out[name] = _bf16_round(w)
+    return out
+
+
+def g19_inputs():
+    r = _rng(19, 1000)
+    x_pre = _bf16_round(randn(r, G19_B, G19_S_PRE, G19_CFG["dim"]))
+    x_dec = _bf16_round(randn(r, G19_N_DEC, G19_B, 1, G19_CFG["dim"]))
+    return x_pre, x_dec
+
+
+def g19_rows():
+    """prefill rows / decode steps whose outputs the fixture keeps"""
+    pre = np.unique(np.concatenate([np.arange(0, 200, 7), np.arange(200, G19_S_PRE - 96, 29), np.arange(G19_S_PRE - 96, G19_S_PRE)]))
+    dec = np.unique(np.concatenate([np.arange(0, 100, 9), np.arange(100, G19_N_DEC - 40, 37), np.arange(G19_N_DEC - 40, G19_N_DEC)]))
+    return pre.astype(np.int64), dec.astype(np.int64)

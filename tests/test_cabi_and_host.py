@@ -385,6 +385,10 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2 * 16
+    # the line verifies itself: an all-reduce over the measurement's own process group counted the ranks
+    rk = rec["ranks"]
+    assert rk["ranks_seen"] == 2 and rk["backend"] == "gloo" and rk["rccl"] is False
+    assert 0 < rk["ms_per_step_rank_min"] <= rk["ms_per_step_rank_max"] and abs(rk["ms_per_step_rank_max"] - rec["ms_per_step"]) < 1e-6
     env["WORLD_SIZE"] = "3"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo"], capture_output=True, text=True,
                        env=env, timeout=120)

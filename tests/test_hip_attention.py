@@ -734,3 +734,56 @@ def test_key_split_block_kernel_matches_plain_walk(nv, orc, tune, B, S, G):
     # run to run: bit-identical (the halves are merged in a fixed order)
     again = nv.selection_attention_hip(Q, K, V, rg)
     assert torch.equal(again, out[1][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("h", [6, 4, 8, 3])
+def test_key_split_other_head_counts_and_f16(nv, orc, tune, dtype, h):
+    """key-split form beyond h = 6 / bf16: with f16 inputs the f16 partial records round at the precision of the output itself (the merge
+    rounds twice), and h != 6 changes the rows per column tile (4, 2 and 5 rows per tile) -- each against the oracle at the north-star
+    tolerance and against the plain walk"""
+    torch.manual_seed(100 + h)
+    B, S, G, D = 2, 2500, 2, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").to(dtype)
+    K = torch.randn(B, G, S, D, device="cuda").to(dtype)
+    V = torch.randn(B, G, S, D, device="cuda").to(dtype)
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, 16, S)
+    tune("SEL_FLAT", 0)
+    out = {}
+    for ks in (0, 1):
+        tune("SEL_KSPLIT", ks)
+        out[ks] = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
+    torch.cuda.synchronize()
+    want, want_lse = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy(),
+                                              return_lse=True)
+    for ks in (0, 1):
+        assert np.abs(out[ks][0].float().cpu().numpy() - want).max() <= TOL[dtype], (ks, h, dtype)
+    fin = np.isfinite(want_lse)
+    assert np.array_equal(np.isfinite(out[1][1].cpu().numpy()), fin) and np.abs(out[1][1].cpu().numpy()[fin] - want_lse[fin]).max() <= 2e-2
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert (out[0][0].float() - out[1][0].float()).abs().max().item() <= 4 * ulp * 1.01  # a rounding step of the output at |O| < 4
+
+
+def test_key_split_records_survive_values_beyond_the_f16_range(nv, orc, tune):
+    """bf16 V with |V| up to 3e5 (beyond f16's 65504): the partial records carry a power-of-two scale, so the key-split form stays finite and
+    agrees with the plain walk wherever that one is (a zero-weight inf record turned into NaN in the merge)"""
+    torch.manual_seed(77)
+    B, S, G, h, D = 1, 1200, 2, 6, 64
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S, D, device="cuda").bfloat16()
+    V = (torch.randn(B, G, S, D, device="cuda") * 1e5).bfloat16()
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, 16, S)
+    tune("SEL_FLAT", 0)
+    out = {}
+    for ks in (0, 1):
+        tune("SEL_KSPLIT", ks)
+        out[ks] = nv.selection_attention_hip(Q, K, V, rg).float()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    assert V.float().abs().max().item() > 65504 * 2
+    scale = out[0].abs().max().item()
+    assert (out[0] - out[1]).abs().max().item() <= scale * 2.0 ** -7
+    want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
+    assert np.abs(out[1].cpu().numpy() - want).max() <= 1e-2 * scale

@@ -755,3 +755,80 @@ def test_m7c_layer_at_config3_size(orc, monkeypatch):
     # random weights give nearly uniform group scores (most 13th / 14th gaps sit below the gate): the gate must still hold rows, every
     # gated row has to agree, and the ungated flips stay a small minority
     assert gated.mean() > 0.3 and same_rows[gated].mean() >= 0.98 and same_rows.mean() >= 0.95
+
+
+# ---- the reference module at the m7c_125m head geometry (g19): the MFMA route inside the module against the REFERENCE module ----------
+def _g19_module(selector, dtype):
+    import golden_inputs as gi
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    g = load_golden("g19_m7c_module")
+    dim, H, G, dk, dv, l, d, ls, n, w = (int(x) for x in g["cfg"])
+    assert (dim, H, G, dk, dv, l, d, ls, n, w) == (768, 12, 2, 64, 64, 32, 16, 64, 16, 512)  # configs/m7c_125m_80g.yaml:1-14
+    m = NSAAttention(dim, H, G, dk, dv, l=l, d=d, l_sel=ls, n_sel=n, w=w, selector=selector)
+    names_shapes = [(str(nm), tuple(int(x) for x in sh if x > 0)) for nm, sh in zip(g["names"], g["shapes"])]
+    state = {k: torch.from_numpy(v) for k, v in gi.g19_state(names_shapes).items()}
+    m.load_state_dict(state)  # the reference's own keys
+    with torch.no_grad():
+        m.gate.fc2.bias.copy_(torch.tensor([-1000.0, 1000.0, -1000.0]))
+    return g, m.cuda().to(dtype).eval()
+
+
+def _row_err(got, ref):
+    err = np.abs(got - ref).max(axis=-1).reshape(-1)
+    return err, float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("selector", ["sequential", "batched"])
+def test_m7c_geometry_prefill_matches_reference_module(selector):
+    """nsa_layer_prefill (bf16: fused projections -> RoPE/append -> MFMA scorer -> top-n -> block-form MFMA selection attention -> gate ->
+    output projection) against the REFERENCE NSAAttention module (CPU fp32, NSA_FORCE_SEL_MASK=1, gate forced onto the selected branch as
+    nsa/tests/test_equiv_full_coverage.py:72; reference path nsa/core/nsa_attention.py:978-1448 batched, 1521-1723 sequential) at
+    dim 768 / 12 heads / G 2 / d_k = d_v = 64 / l 32 / d 16 / l' 64 / n 16, S = 4096.  Weights and inputs are bf16-representable, so
+    the two sides differ by the bf16 roundings inside the layer (Q/K/V and O are bf16 tensors here, fp32 there) -- and, on a few rows,
+    by a selection flipped on a near tie of the bf16 scores.  Bars: the typical row within the north-star bf16 tolerance scaled to the
+    output range; at most 3 % of the rows beyond 4x that."""
+    import golden_inputs as gi
+
+    g, m = _g19_module(selector, torch.bfloat16)
+    x_pre, _ = gi.g19_inputs()
+    x = torch.from_numpy(x_pre).cuda().bfloat16()
+    tag = "seq" if selector == "sequential" else "bat"
+    with torch.no_grad():
+        out, kv = m(x, m.new_kv(x.shape[0], x.shape[1], "cuda", torch.bfloat16), prefill=True)
+    torch.cuda.synchronize()
+    rows = g["rows_pre"]
+    err, scale = _row_err(out.float().cpu().numpy()[:, rows], g[f"out_pre_{tag}"])
+    tol = 1e-2 * max(scale, 1.0)
+    print(f"g19 prefill {selector}: rows {err.size}, |ref| max {scale:.3f}, row err median {np.median(err):.2e} p90 {np.percentile(err, 90):.2e} "
+          f"max {err.max():.2e}; rows beyond {tol:.1e}: {(err > tol).mean():.4f}, beyond 4x: {(err > 4 * tol).mean():.4f}")
+    assert torch.isfinite(out.float()).all()
+    assert np.median(err) <= tol and (err > 4 * tol).mean() <= 0.03
+    assert m.get_fallback_counters()["total_fallbacks"] == 0
+
+
+def test_m7c_geometry_decode_matches_reference_module():
+    """nsa_layer_decode_step (bf16; the fused decode scorer + selector + attention launch inside) against the REFERENCE module decoding
+    2200 tokens from an empty cache (nsa/core/nsa_attention.py:545-976), outputs of sampled steps; same bars as the prefill test"""
+    import golden_inputs as gi
+
+    g, m = _g19_module("sequential", torch.bfloat16)
+    _, x_dec = gi.g19_inputs()
+    x = torch.from_numpy(x_dec).cuda().bfloat16()
+    rows = set(int(r) for r in g["rows_dec"])
+    outs = []
+    with torch.no_grad():
+        kv = m.new_kv(x.shape[1], x.shape[0], "cuda", torch.bfloat16)
+        for i in range(x.shape[0]):
+            o, kv = m(x[i], kv, prefill=False)
+            if i in rows:
+                outs.append(o.float())
+    torch.cuda.synchronize()
+    got = torch.stack(outs).cpu().numpy()
+    err, scale = _row_err(got, g["out_dec"])
+    tol = 1e-2 * max(scale, 1.0)
+    print(f"g19 decode: steps {err.size}, |ref| max {scale:.3f}, step err median {np.median(err):.2e} p90 {np.percentile(err, 90):.2e} "
+          f"max {err.max():.2e}; beyond {tol:.1e}: {(err > tol).mean():.4f}, beyond 4x: {(err > 4 * tol).mean():.4f}")
+    assert np.isfinite(got).all() and kv.t == x.shape[0]
+    assert np.median(err) <= tol and (err > 4 * tol).mean() <= 0.03
+    assert m.get_fallback_counters()["total_fallbacks"] == 0

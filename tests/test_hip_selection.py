@@ -152,7 +152,14 @@ def test_g11_small_chains(nv):
         pg_dev = nv.selection_scores(dev(Q), dev(Kc), m)
         rb_dev = nv.select_topn_ranges_batched(pg_dev, m, n_top, S)
         same = (rb_dev.cpu().numpy() == g[f"c{ci}_r_bat"]).all(axis=(-1, -2))
-        assert same.mean() > 0.98  # device scores differ by ~1e-7: near-tie rows may flip
+        # device scores differ from the reference's by ~1e-7 (checked: < 2e-6), so a row may flip only where its last picked and first
+        # rejected ranking keys are closer than that: every row whose gap in the REFERENCE p_grp exceeds 4e-6 must match bit for bit
+        # (the gate of test_g10_ranges_from_q_k_are_exact_where_the_score_gap_allows; on these fixtures it lets every row through)
+        assert np.abs(pg_dev.cpu().numpy() - g[f"c{ci}_p_grp"]).max() < 2e-6
+        ts_all = np.repeat(np.arange(S), 1)
+        gaps = np.stack([_topn_gap(g[f"c{ci}_p_grp"][b_].reshape(-1, m.S_sel), ts_all, n_top=n_top, l_sel=ls, G=G) for b_ in range(Q.shape[0])])
+        gated = gaps.reshape(same.shape) > 4e-6
+        assert gated.mean() > 0.9 and same[gated].all(), (ci, float(gated.mean()), float(same.mean()))
         O = nv.selection_attention_hip(dev(Q), dev(K), dev(V), dev(g[f"c{ci}_r_bat"]))
         assert np.abs(O.cpu().numpy() - g[f"c{ci}_O"]).max() <= 1e-3
 
@@ -497,7 +504,7 @@ def _topn_gap(p_grp_rows, ts, n_top=16, l_sel=64, G=2):
                 ok[f] = False
         k = sorted(key[ok].tolist(), reverse=True)
         kk = n_top - 3
-        if len(k) > kk:
+        if kk >= 1 and len(k) > kk:
             gaps[r] = k[kk - 1] - k[kk]
     return gaps
 
@@ -595,3 +602,40 @@ def test_fused_decode_with_a_meta_from_before_the_first_compressed_token(nv, tun
     torch.cuda.synchronize()
     for O, r in outs[:2]:
         assert torch.equal(r, outs[2][1]) and torch.equal(O, outs[2][0])
+
+
+def test_scorer_64bit_output_offsets(nv, orc):
+    """S = 262144 with G = 2: one sequence's p_grp is S G S_sel = 2^31 elements (8 GiB), so the fused scorer must form its output offsets
+    in 64 bits (`big_out`, sel_scores_mfma.hip) -- rows from t = 131072 on lie beyond a 32-bit element offset.  Sampled rows on both
+    sides of that line against the oracle chain on the bf16-rounded inputs (compute_pcmp_all -> Eq.9 -> Eq.10:
+    nsa/core/selection_scorer.py:42-61, 89-116; nsa_attention.py:1091), with causal_skip = 2 as the hot path calls it (entries no
+    selector reads stay unwritten: compared on the readable prefix), and the ranges of those rows from the device scores through the
+    batched selector against the oracle's on the same scores."""
+    S, G, h, D, n = 262144, 2, 6, 64, 16
+    m = nv.build_block_meta(S, 32, 16, 64, n, 512)
+    om = orc.build_block_meta(S, 32, 16, 64, n, 512)
+    assert m.S_sel == 4096 and S * G * m.S_sel >= 2 ** 31
+    g = torch.Generator(device="cuda")
+    g.manual_seed(262)
+    Q = torch.randn(1, S, G, h, D, device="cuda", generator=g).bfloat16()
+    Kc = torch.randn(1, G, m.S_cmp, D, device="cuda", generator=g).bfloat16()
+    pg = nv.selection_scores(Q, Kc, m, causal_skip=True, leave_skipped=True)
+    torch.cuda.synchronize()
+    ts = np.array([63, 4097, 131071, 131072, 131073, 200000, 262100, 262143])
+    Qr = Q[0, torch.from_numpy(ts).cuda()].float().cpu().numpy()[None]  # [1, rows, G, h, D]
+    _, ref = orc.map_pcmp_to_pslc_and_pgrp(orc.compute_pcmp_all(Qr, Kc.float().cpu().numpy(), 0.125)[0], om)  # [rows, G, S_sel]
+    got = pg[0, torch.from_numpy(ts).cuda()].cpu().numpy()
+    for i, t in enumerate(ts):
+        nvalid = (t + 1) // 64  # blocks a selector may read at row t
+        assert nvalid >= 1 or t < 63
+        assert np.abs(got[i, :, :nvalid] - ref[i, :, :nvalid]).max() < 4e-6, int(t)
+    # the rows' ranges: device scores -> device selector against the oracle's selector on the same scores (bit-exact)
+    import nsa_vibe_amd.selection_scorer as ss
+
+    t_rows = dev(np.repeat(ts, G).astype(np.int32))
+    rows = torch.from_numpy(got.copy()).cuda().reshape(-1, m.S_sel)
+    for i, t in enumerate(ts):  # (the unwritten tail holds whatever the allocation held: blank it for the oracle, neither side reads it)
+        rows[G * i:G * i + G, (t + 1) // 64:] = 0
+    rs = ss._select(rows, len(ts) * G, 1, G, 0, t_rows, m, n, True, 2, 0, 1, n).cpu().numpy()
+    want = orc.select_topn_ranges_rows(rows.cpu().numpy(), np.repeat(ts, G), om, n, True, 2)
+    assert norm(rs) == norm(want)

@@ -234,3 +234,24 @@ def test_g17_head_causal_parity_mode(orc, name):
     O = orc.sel_attention_head_causal_parity(g["Q"][:, None], g["K"], g["V"], g["ranges"][:, None])[:, 0]
     assert np.abs(O - g["O"]).max() <= 1e-5
     assert not O[0, 0].any()
+
+
+def test_g19_recipe_and_fixture_are_consistent():
+    """g19 (reference module at the m7c geometry): the fixture holds outputs only, weights / inputs are regenerated from the PCG64
+    recipes -- check the recipe is bf16-representable and matches the fixture's bookkeeping (names, shapes, sampled rows)"""
+    import torch
+
+    g = load_golden("g19_m7c_module")
+    names_shapes = [(str(nm), tuple(int(x) for x in sh if x > 0)) for nm, sh in zip(g["names"], g["shapes"])]
+    assert {"W_Q.weight", "W_K_sel.weight", "W_V_sel.weight", "out.weight", "gate.fc1.weight", "gate.fc2.bias"} <= {n for n, _ in names_shapes}
+    state = gi.g19_state(names_shapes)
+    for k, v in state.items():
+        assert np.array_equal(torch.from_numpy(v).bfloat16().float().numpy(), v), k
+    assert state["W_Q.weight"].shape == (768, 768) and state["W_K_sel.weight"].shape == (128, 768)
+    x_pre, x_dec = gi.g19_inputs()
+    assert x_pre.shape == (1, 4096, 768) and x_dec.shape == (2200, 1, 1, 768)
+    assert np.array_equal(torch.from_numpy(x_pre).bfloat16().float().numpy(), x_pre)
+    rows_pre, rows_dec = gi.g19_rows()
+    assert np.array_equal(rows_pre, g["rows_pre"]) and np.array_equal(rows_dec, g["rows_dec"])
+    assert g["out_pre_seq"].shape == (1, len(rows_pre), 768) and g["out_dec"].shape == (len(rows_dec), 1, 1, 768)
+    assert np.isfinite(g["out_pre_seq"]).all() and np.isfinite(g["out_pre_bat"]).all() and np.isfinite(g["out_dec"]).all()
