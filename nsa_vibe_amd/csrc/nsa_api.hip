@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, 1, -1, -1, 0};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP", "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, 1, -1, -1, 0, -1, -1, 1};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -633,12 +633,14 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
     const bool wg_attn = sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, ksb, ksg, kss, vsb, vsg, vss, Q, K, V) && S_kv >= 1 &&
                          (int64_t)S_kv * 128 < ((int64_t)1 << 31);
     const int stencil = (l == 2 * d && l_sel == 4 * d) ? 1 : 0;  // Eq.9 in closed form (the fused kernel then reads no CSC arrays)
+    if (decode_step_supported((int64_t)B * G, dtype, h, Dk, Dv, S_cmp, S_sel, S_kv, l, d, l_sel, n_top, t_token, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg, vss, Q, K_cmp,
+                              K, V)) {  // scores -> statistics -> Eq.9/10 -> sequential top-n -> selection attention: ONE launch, O is final
+        if (ns_used) *ns_used = 1;
+        return launch_decode_step(Q, K_cmp, K, V, O, ranges_out, B, G, h, S_cmp, S_sel, S_kv, n_top, t_token, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg,
+                                  vss, dtype, sc, w, a, (hipStream_t)stream);
+    }
+    (void)wg_attn;
     if (decode_score_select_supported(dtype, h, Dk, S_cmp, S_sel, kcb, kcg, kcs, Q, K_cmp, (int64_t)B * G)) {
-        if (wg_attn) {  // scores -> statistics -> Eq.9/10 -> sequential top-n -> selection attention: ONE launch, O is final
-            if (ns_used) *ns_used = 1;
-            return launch_decode_score_select_attend(Q, K_cmp, K, V, O, B, G, h, Dk, S_cmp, S_kv, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg, vss, csc_ptr,
-                                                     csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype, sc, ranges_out, (hipStream_t)stream, stencil);
-        }
         // scores -> statistics -> Eq.9/10 -> sequential top-n in one launch (bit-identical to the route below)
         rc = launch_decode_score_select(Q, K_cmp, B, G, h, Dk, S_cmp, kcb, kcg, kcs, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token,
                                         dtype, sc, ranges_out, (hipStream_t)stream, nullptr, stencil);

@@ -49,6 +49,9 @@ enum Tune {
     TUNE_SEL_FLAT,          // NSA_HIP_SEL_FLAT: block-form attention with h = 6, 1 = 8 rows on 3 column tiles (no idle columns), 0 = on 4 tiles, -1 = by context length
     TUNE_SEL_KSPLIT,        // NSA_HIP_SEL_KSPLIT: block-form attention with the keys of a pair split over two XCD groups: -1 by shape, 0 never, 1 always
     TUNE_DECODE_STOP,       // NSA_HIP_DECODE_STOP: measurement aid, the fused decode kernel returns after phase N (1 logits, 2 scores, 3 top-n); 0 = run all
+    TUNE_DECODE_WAVES,      // NSA_HIP_DECODE_WAVES: waves per row workgroup of the decode kernels, -1 by the number of rows, 8 or 16
+    TUNE_DECODE_SPLIT,      // NSA_HIP_DECODE_SPLIT: fused decode step, workgroups that share the logits phase of one row, -1 by shape, N forces N
+    TUNE_DECODE_STEP,       // NSA_HIP_DECODE_STEP: 1 = the one-launch decode step of sel_decode_fused.hip wherever it applies (default), 0 = the round-2 kernels
     TUNE_COUNT
 };
 int tuning(Tune t);
@@ -115,6 +118,34 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// ---- cross-lane steps without the LDS crossbar (gfx950) --------------------------------------------------------------------------------
+// __shfl_xor(v, 16 / 32) goes through ds_bpermute (an LDS-crossbar round trip, ~100 cycles, on a dependent chain); v_permlane16_swap /
+// v_permlane32_swap exchange whole rows / halves of two registers in one VALU instruction.  With both operands = v, every lane ends up with
+// (value of the even row or lower half, value of the odd row or upper half) of its pair: one more op gives the xor-16 / xor-32 butterfly step.
+// IEEE add and max are commutative, so the result has the bits of `v op __shfl_xor(v, 16 / 32)`.
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_add(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lane i reads lane (i + N) mod 16 of its 16-lane row (DPP row_ror).  For a value that is already symmetric under xor of every higher bit
+// of the lane index (the state after the earlier steps of a butterfly reduction) this IS the xor-N partner.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 | N, 0xf, 0xf, false));
+}
+
 // make LDS traffic of this wave visible to its own later LDS reads (wave-private regions only:
 // DS operations of one wave execute in order, the fence only pins the compiler).
 __device__ __forceinline__ void wave_lds_fence() {

@@ -27,10 +27,13 @@ int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int 
                                const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l_sel, int n_top,
                                int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st, const DecAttnArgs *attend,
                                int stencil);
-int launch_decode_score_select_attend(const void *Q, const void *Kc, const void *K, const void *V, void *O, int B, int G, int h, int Dk, int S_cmp,
-                                      int S_kv, int64_t csb, int64_t csg, int64_t css, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
-                                      int64_t vsg, int64_t vss, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
-                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st,
-                                      int stencil);
+// the one-launch decode step (sel_decode_fused.hip): default block geometry, bf16 / f16, Dk = Dv = 64
+bool decode_step_supported(int64_t R, int dtype, int h, int Dk, int Dv, int S_cmp, int S_sel, int S_kv, int l, int d, int l_sel, int n_top, int t_token,
+                           int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
+                           const void *Q, const void *Kc, const void *K, const void *V);
+size_t decode_step_workspace(int64_t R, int h, int S_cmp);
+int launch_decode_step(const void *Q, const void *Kc, const void *K, const void *V, void *O, int32_t *ranges_out, int B, int G, int h, int S_cmp,
+                       int S_sel, int S_kv, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss,
+                       int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace nsa

@@ -1,0 +1,474 @@
+// One decode step of the selected branch in ONE launch (round 3): logits -> softmax statistics -> Eq.9 / Eq.10 -> sequential top-n ->
+// selection attention, for the default block geometry (l = 2d, l' = 4d = 64: Eq.9 is the 5-tap stencil of SURVEY.md 8(a) A3).
+// Replaces, per step: compute_pcmp_all -> map_pcmp_to_pslc_batched -> sum(dim=3) -> select_topn_ranges -> the selection executor
+// (nsa/core/nsa_attention.py:651-672, 704-830; nsa/core/selection_scorer.py:42-61, 89-116, 124-249).
+//
+// Why a new kernel (profiles/r02/m_decode_timeline.txt): the round-2 kernel spent 6.5 of its 20 us (B = 64, 16k context) in a chain of
+// on-chip phases between its two memory phases -- logits -> LDS -> barrier -> statistics -> barrier -> taps -> barrier -> head sums ->
+// barrier -> top-n -> ranges -> barrier -> segment table / scan -> gather -- with HBM idle all the while, at one workgroup per CU.  Here:
+//   * the logits never leave the registers: the MFMA accumulators of a wave hold 4 consecutive compressed rows = ONE selection block
+//     per lane group, so Eq.9 is in-lane except one lane rotation and Eq.10 is a DPP row-shift add (the prefill scorer's trick,
+//     sel_scores_mfma.hip); after ONE barrier (the per-chunk (max, sum) records and the halo logits of the chunk edges through LDS)
+//     every wave forms the per-head log-sum-exp for itself -- in the butterfly order of wave_max / wave_sum, so p_grp has the bits of the
+//     three-kernel route (decode_logits_mfma_kernel -> decode_pgrp_kernel) -- and writes its blocks' group scores;
+//   * the selector leaves the picked BLOCKS in LDS (sel_select_row.hpp), wave e mod NW gathers block e: no range -> segment -> chunk
+//     translation on the critical path; the merged ranges (the path's second result) are stored while the gather is in flight;
+//   * NW = 8 (two workgroups per CU) from 257 rows on: one row's chain overlaps another row's memory phases (sel_attn_decode.hpp);
+//   * long contexts / few rows: the K_cmp sweep of a row is SPLIT over NS workgroups (all on one XCD: they meet in its L2); each leaves
+//     its scaled logits and chunk records in the workspace and takes a ticket, the LAST one to arrive carries on with the row (no
+//     workgroup ever waits for another: no co-residency assumption, nothing to dead-lock) -- early rows reach their chain and gather
+//     while later rows still sweep, which is the overlap the single-workgroup form cannot have at 64k.
+// Results: ranges identical, O bit-identical to the three separate launches (tests: test_fused_decode_step,
+// test_fused_decode_scorer_equals_three_kernel_route).
+#include <mutex>
+#include <unordered_map>
+
+#define DEC_TS(i)  // (the shared device functions' own stamps belong to the round-2 kernel's timeline: this kernel stamps with DS_TS)
+#include "nsa_internal.hpp"
+#include "sel_attn_decode.hpp"
+#include "sel_attn_params.hpp"
+#include "sel_select_row.hpp"
+
+namespace nsa {
+
+#ifdef NSA_DEC_TS  // make TIMELINE=1: s_memrealtime stamps of the workgroup(s) of the middle row, read back by nsa_debug_read_ts2 (tools/decode_timeline.py)
+static __device__ long long g_ts2[32];
+#define DS_TS(i) do { if (ts_on && threadIdx.x == 0) g_ts2[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DS_TS(i)
+#endif
+
+struct DecStepParams {
+    const void *Q;   // [R,h,64]
+    const void *Kc;  // [B,G,S_cmp,64] strided
+    float *part_g;   // SPLIT: [R][h][64][2] per-chunk (max, sum exp2)
+    float *halo_g;   // SPLIT: [R][64][16] scaled logit of every chunk's last row, per head
+    float *pg_g;     // SPLIT: [R][2048] group scores of the row's blocks
+    int *cnt;        // SPLIT: [2][R] arrivals (records published) and tickets (scores published); zero between launches
+    int R, G, h, S_cmp, S_sel, NS, nchunk, cpg, t_token;
+    int64_t csb, csg, css;
+    float c2;
+};
+
+constexpr int DSTEP_PART = 16 * 64 * 2;  // floats: [head][chunk][2]
+constexpr int DSTEP_HALO = 64 * 16;      // floats: [chunk][head] scaled logit of the chunk's last row
+static size_t dstep_lds(int nw) { return (size_t)nw * DEC_ATT_TILE + sizeof(float) * nw * 16 + sizeof(int) * (128 + 68 + 4); }
+
+template <typename T, int NW, bool SPLIT, int HC>
+__global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT) {
+    using M = MfmaT<T>;
+    using x8 = typename M::x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // the score phases live where the V tiles of the gather will be: part | halo | pg
+    float *part = (float *)lds;
+    float *halo = part + DSTEP_PART;
+    float *pg = halo + DSTEP_HALO;  // [S_sel]
+    float *mlw = (float *)(lds + NW * DEC_ATT_TILE);  // [NW][16] per-wave copy of the per-head log-sum-exp
+    int *scr = (int *)(mlw + NW * 16);                // [128] run extraction of the selector
+    int *list = scr + 128;                            // [68] picked blocks, ascending
+    int *misc = list + 68;                            // [0] number of picked blocks, [1] ticket
+
+    const int lane = lane_id(), wave = uniform((int)(threadIdx.x >> 6)), rho = lane & 15, q = lane >> 4;
+    const int h = P.h;
+    int row = blockIdx.x, sp = 0;
+    if constexpr (SPLIT) {  // the NS workgroups of a row sit on one XCD (workgroups go round-robin over the 8 XCDs)
+        const int per = 8 * P.NS, grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
+        row = grp * 8 + (rem & 7);
+        sp = rem >> 3;
+        if (row >= P.R) return;
+    }
+    [[maybe_unused]] const bool ts_on = row == P.R / 2;
+    DS_TS(0);
+    const int g = row % P.G;
+    const int64_t b = row / P.G;
+    const int hc = min(rho, h - 1);  // head of this lane's column (columns >= h repeat the last head: their results are never used)
+
+    // ---- phase 1: logits of this workgroup's chunks (64 compressed rows each = MFMA rows; heads = columns), up to two per wave,
+    // all loads out at once
+    x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *(const x8 *)((const T *)P.Q + ((int64_t)row * h + hc) * 64 + 32 * s + 8 * q);
+    const T *kb = (const T *)P.Kc + b * P.csb + (int64_t)g * P.csg;
+    const int c_lo = SPLIT ? sp * P.cpg : 0, c_hi = SPLIT ? min(P.nchunk, c_lo + P.cpg) : P.nchunk;
+    constexpr int CPW = 2;
+    x8 a[CPW][4][2];
+    f32x4 acc[CPW][4];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = c_lo + wave + NW * k;
+        if (c < c_hi) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = min(c * 64 + 16 * u + rho, P.S_cmp - 1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[k][u][s] = *(const x8 *)(kb + (int64_t)r * P.css + 32 * s + 8 * q);
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < P.S_sel; i += NW * 64) pg[i] = 0.f;  // blocks without a compressed row keep a zero score
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = c_lo + wave + NW * k;
+        if (c < c_hi) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) z = M::mma(a[k][u][s], qf[s], z);
+                acc[k][u] = z;
+            }
+            // scaled logits and the chunk's (max, sum exp2) per head: the arithmetic of decode_logits_mfma_kernel
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[k][u][j] * P.c2;
+                    acc[k][u][j] = v;
+                    if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) m = fmaxf(m, v);
+                }
+            m = xor32_max(xor16_max(m));  // (= the xor-16, xor-32 shuffle steps of decode_logits_mfma_kernel: same bits)
+            float l = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(acc[k][u][j] - m);
+            l = xor32_add(xor16_add(l));
+            if constexpr (SPLIT) {
+                if (rho < h) {  // write-through (sc1) stores: no release fence needed (cdna guide, Guideline 16 R1)
+                    if (q == 0)
+                        __hip_atomic_store((unsigned long long *)(P.part_g + (((int64_t)row * h + rho) * 64 + c) * 2),
+                                           ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q == 3)
+                        __hip_atomic_store((unsigned *)(P.halo_g + ((int64_t)row * 64 + c) * 16 + rho), __float_as_uint(acc[k][3][3]), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (rho < h) {
+                    if (q == 0) *(f32x2 *)(part + (rho * 64 + c) * 2) = (f32x2){m, l};
+                    if (q == 3) halo[c * 16 + rho] = acc[k][3][3];  // row 64 c + 63: the half tap of the next chunk's first block
+                }
+            }
+        }
+    }
+    DS_TS(1);
+    if constexpr (SPLIT) {
+        // The NS workgroups of the row meet ONCE: each has published the (max, sum) records and the edge logits of its chunks -- a few
+        // hundred bytes, write-through (sc1) stores, every storing wave drained, then ONE lane's agent-scope add behind the workgroup
+        // barrier (the hand-off form of the CDNA guide, Guideline 16 R1) -- and waits until all NS have (one lane polls with sc1 loads and
+        // s_sleep; the others wait at the barrier it then joins).  The logits themselves never leave the registers: with the row's
+        // log-sum-exp every workgroup scores its OWN blocks.  (First form of this kernel: the last arriver re-read all logits from the
+        // workspace -- 98 KB per row at 64k, 3.3 us at the ~30 GB/s one CU pulls from memory, and scored all 64 chunks alone.)
+        // The wait needs the row's workgroups resident together: the host launches this form only while R NS workgroups fit the chip at
+        // once, and the poll is bounded (a trap, not a hang, should that ever not hold).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DS_TS(2);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(P.cnt + row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int it = 0; __hip_atomic_load(P.cnt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.NS; ++it) {
+                __builtin_amdgcn_s_sleep(2);
+                if (it > (1 << 22)) __builtin_trap();
+            }
+        }
+        __syncthreads();
+        DS_TS(3);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the compiler from moving the loads below above this point)
+        // the row's records and edge logits -> LDS, one sc1 load per thread
+        for (int i = threadIdx.x; i < h * 64; i += NW * 64) {
+            const int hh = i >> 6, idx = i & 63;
+            if (idx < P.nchunk) {
+                const unsigned long long r = __hip_atomic_load((const unsigned long long *)(P.part_g + (((int64_t)row * h + hh) * 64 + idx) * 2), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                *(f32x2 *)(part + (hh * 64 + idx) * 2) = (f32x2){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
+            }
+        }
+        for (int i = threadIdx.x; i < P.nchunk * 16; i += NW * 64)
+            if ((i & 15) < h) halo[i] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.halo_g + (int64_t)row * 64 * 16 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        DS_TS(4);
+    } else {
+        __syncthreads();
+        DS_TS(4);
+    }
+
+    // ---- phase 2a: per-head log-sum-exp of the row's logits from the chunk records, by every wave for itself.  One 16-lane row of the
+    // wave per head, lane i holds records i, i+16, i+32, i+48: ((a_i + a_{i+32}) + (a_{i+16} + a_{i+48})) then xor 8, 4, 2, 1 is the
+    // summation tree of wave_sum over 64 lanes (decode_pgrp_kernel / the round-2 fused kernel): same bits.
+    const int nr4 = (P.nchunk + 15) >> 4;  // records per lane that exist at all (a context of 16k has 16 chunks: one)
+    for (int h0 = 0; h0 < h; h0 += 4) {
+        const int hh = h0 + q;
+        float mv[4], lv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = rho + 16 * i;
+            mv[i] = -INFINITY;
+            lv[i] = 0.f;
+            if (i < nr4 && hh < h && idx < P.nchunk) {
+                const f32x2 r = *(const f32x2 *)(part + (hh * 64 + idx) * 2);
+                mv[i] = r[0];
+                lv[i] = r[1];
+            }
+        }
+        float m = fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3]));
+        m = fmaxf(m, row_ror<8>(m));  // butterfly over the 16 lanes of the row by DPP rotations (nsa_common.hpp: no LDS crossbar on the chain)
+        m = fmaxf(m, row_ror<4>(m));
+        m = fmaxf(m, row_ror<2>(m));
+        m = fmaxf(m, row_ror<1>(m));
+        float av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // (a record that does not exist adds +0: exact, so skipping its exponential changes nothing)
+            av[i] = (i < nr4 && rho + 16 * i < P.nchunk) ? lv[i] * __builtin_amdgcn_exp2f(mv[i] - m) : 0.f;
+        float s = (av[0] + av[2]) + (av[1] + av[3]);
+        s += row_ror<8>(s);
+        s += row_ror<4>(s);
+        s += row_ror<2>(s);
+        s += row_ror<1>(s);
+        if (rho == 0 && hh < h) mlw[wave * 16 + hh] = m + __builtin_amdgcn_logf(s);
+    }
+    wave_lds_fence();
+    const float ml = mlw[wave * 16 + hc];
+    DS_TS(5);
+
+    // ---- phase 2b: p = exp2(x - ml), Eq.9 stencil (1/2, 1, 1, 1, 1/2 over rows 4j-1 .. 4j+3, ascending), Eq.10 head sum (ascending h)
+    auto blocks_of_chunk = [&](int c, const f32x4 (&v)[4], float hprev) {
+        float rot_prev = c > 0 ? __builtin_amdgcn_exp2f(hprev - ml) : 0.f;  // p of row 64 c - 1 (a chunk that exists has its predecessor complete)
+        const bool tail = c * 64 + 64 > P.S_cmp;  // only the row's last chunk can reach past S_cmp (wave uniform): the others need no row masks
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = __builtin_amdgcn_exp2f(v[u][k] - ml);
+            if (tail) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c * 64 + 16 * u + 4 * q + k >= P.S_cmp) p[k] = 0.f;
+            }
+            const float rot = __shfl(p[3], (lane + 48) & 63, 64);  // row 4j - 1 = last row of the previous lane group (previous sub-tile for q = 0)
+            const float tapm1 = (q == 0) ? rot_prev : rot;
+            rot_prev = rot;
+            float slc = fmaf(0.5f, tapm1, p[0]);  // (0.5 x is exact: the fma rounds once, like the separate product and sum of the reference order)
+            slc += p[1];
+            slc += p[2];
+            slc = fmaf(0.5f, p[3], slc);
+            // heads of the group = columns 0 .. h-1 of this 16-lane row: lane 0 collects them in ascending order by DPP row shifts.  HC = the
+            // group size at compile time (straight-line code); HC = 0: any h <= 16 -- columns >= h enter as zeros (p >= 0: adding +0 is exact),
+            // so the 15 shifted adds run unconditionally (a scalar branch per possible head cost 2 us per step at 64k)
+            float grp;
+#define NSA_DS_HS(K) grp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x100 | K, 0xf, 0xf, true));
+            if constexpr (HC == 6) {
+                const float src = slc;
+                grp = slc;
+                NSA_DS_HS(1) NSA_DS_HS(2) NSA_DS_HS(3) NSA_DS_HS(4) NSA_DS_HS(5)
+            } else {
+                const float src = rho < h ? slc : 0.f;
+                grp = src;
+                NSA_DS_HS(1) NSA_DS_HS(2) NSA_DS_HS(3) NSA_DS_HS(4) NSA_DS_HS(5) NSA_DS_HS(6) NSA_DS_HS(7) NSA_DS_HS(8)
+                NSA_DS_HS(9) NSA_DS_HS(10) NSA_DS_HS(11) NSA_DS_HS(12) NSA_DS_HS(13) NSA_DS_HS(14) NSA_DS_HS(15)
+            }
+#undef NSA_DS_HS
+            const int j = 16 * c + 4 * u + q;
+            if (rho == 0 && j < P.S_sel) {
+                if constexpr (SPLIT) __hip_atomic_store((unsigned *)(P.pg_g + (int64_t)row * 2048 + j), __float_as_uint(grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else pg[j] = grp;
+            }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = c_lo + wave + NW * k;
+        if (c < c_hi) blocks_of_chunk(c, acc[k], c > 0 ? halo[(c - 1) * 16 + hc] : 0.f);
+    }
+    if constexpr (SPLIT) {
+        // second meeting, nobody waits: the scores of this workgroup's blocks are published (sc1, drained), one lane takes a ticket; the
+        // workgroup that draws the last one reads the row's scores (<= 4 KB) and carries on with the row, the others are done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tk = __hip_atomic_fetch_add(P.cnt + P.R + row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == P.NS - 1) {  // every workgroup of the row is past the first meeting: both words go back to zero for the next launch
+                __hip_atomic_store(P.cnt + row, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(P.cnt + P.R + row, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            misc[1] = tk;
+        }
+        __syncthreads();
+        if (misc[1] != P.NS - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = threadIdx.x; j < min(P.S_sel, 16 * P.nchunk); j += NW * 64)
+            pg[j] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.pg_g + (int64_t)row * 2048 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    DS_TS(6);
+    __syncthreads();
+    DS_TS(7);
+
+    // ---- phase 3: top-n + forced blocks (one wave); the picked blocks go to LDS for the gather, the merged ranges to the caller.
+    // (Tried and dropped, profiles/r03/decode_notes.txt: the selection as a rank problem over the whole workgroup -- every block's rank by
+    // all-pairs compares of 64-bit (key, ~index) images, three short phases instead of the threshold search's dependent rounds.  All-pairs
+    // over 256 slots is 65,536 compares = ~1 us of VALU issue on one CU even at full rate, and v_cmp_gt_u64 is not full rate: 2.1 + 0.7 us
+    // at 16k context against 2.8 us for this wave's search, 5.9 against 4.5 us at 64k.)
+    int rs = 0, re = 0;
+    if (wave == 0) {
+        int nb = 0;
+        switch (cand) {
+            case 1: select_topn_row_regs<1>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 2: select_topn_row_regs<2>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 4: select_topn_row_regs<4>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 8: select_topn_row_regs<8>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 16: select_topn_row_regs<16>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            default: select_topn_row_regs<32>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+        }
+        if (lane == 0) misc[0] = nb;
+    }
+    DS_TS(8);
+    __syncthreads();  // the scores are dead from here on: their space holds the V tiles
+    if (wave == 0 && lane < SP.W) {
+        int32_t *out = SP.out + (int64_t)row * SP.W * 2;
+        out[2 * lane] = rs;
+        out[2 * lane + 1] = re;
+    }
+    const int NC = uniform(misc[0]);
+    // ---- phase 4: selection attention over the picked blocks (wave e mod NW gathers block e; partials merged through LDS)
+    const ListChunks ch{list, min(P.t_token + 1, AT.S_kv)};
+    DS_TS(9);
+    decode_attend_chunks<T, NW>(AT, row, ch, NC, lds, qf);
+    DS_TS(10);
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------------
+// arrival tickets of the split form: owned by the library, one zeroed array per (device, stream) -- launches of one stream are ordered
+// and every launch leaves its tickets at zero, launches of different streams never share an array
+static int *decode_tickets(hipStream_t st, int64_t rows) {
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, std::pair<int *, int64_t>> tab;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const uint64_t key = ((uint64_t)(uintptr_t)st << 8) ^ (uint64_t)dev;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tab.find(key);
+    if (it != tab.end() && it->second.second >= rows) return it->second.first;
+    const int64_t n = rows < 4096 ? 4096 : rows * 2;
+    int *p = nullptr;
+    if (hipMalloc(&p, sizeof(int) * n) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(int) * n) != hipSuccess) return nullptr;  // (synchronous: once per stream; an outgrown array stays allocated -- a launch may still use it)
+    tab[key] = {p, n};
+    return p;
+}
+
+size_t decode_step_workspace(int64_t R, int h, int S_cmp) {  // split form: chunk records, edge logits, group scores of every row
+    (void)S_cmp;
+    return sizeof(float) * (size_t)R * ((size_t)h * 64 * 2 + 64 * 16 + 2048);
+}
+
+static int device_cu_count() {
+    static std::mutex mu;
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
+// waves per row workgroup and workgroups per row (1 = the unsplit kernel); false = this shape is not for the one-launch step.
+// The workgroups of a split row meet inside the launch (one of them polls for the others): R * NS of them must be resident together.
+static bool decode_step_plan(int64_t R, int nchunk, int *nw_out, int *ns_out) {
+    const int nw = dec_att_waves(R);
+    const int64_t slots = (int64_t)device_cu_count() * (nw == 16 ? 1 : 2);  // 1024-thread workgroups hold a CU each (LDS), 512-thread ones share it
+    const int mode = tuning(TUNE_DECODE_SPLIT);
+    int ns = (nchunk + 2 * nw - 1) / (2 * nw);  // at most two chunks per wave (the accumulators of a wave's chunks stay in registers)
+    if (ns > 1 && R * ns > slots) return false;
+    if (mode > 0) {
+        int want = mode < ns ? ns : (mode > nchunk ? nchunk : mode);
+        while (want > ns && R * want > slots) --want;
+        ns = want;
+    } else {
+        const int ns1 = (nchunk + nw - 1) / nw;  // one chunk per wave
+        if (ns1 > ns && R * ns1 <= slots) ns = ns1;
+        // few rows: spread the K_cmp sweep over more CUs (one CU pulls ~30 GB/s from memory whatever its waves do: MI355X guide, gather table)
+        while (ns < 16 && R * ns * 2 <= slots / 2 && (nchunk + ns * 2 - 1) / (ns * 2) >= 2) ns *= 2;
+    }
+    *nw_out = nw;
+    *ns_out = ns;
+    return true;
+}
+
+bool decode_step_supported(int64_t R, int dtype, int h, int Dk, int Dv, int S_cmp, int S_sel, int S_kv, int l, int d, int l_sel, int n_top, int t_token,
+                           int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
+                           const void *Q, const void *Kc, const void *K, const void *V) {
+    if (tuning(TUNE_DECODE_STEP) == 0 || tuning(TUNE_DECODE_UNFUSED) > 0) return false;
+    int nw, ns;
+    if (R < 1 || S_cmp < 1 || !decode_step_plan(R, (S_cmp + 63) / 64, &nw, &ns)) return false;
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16 && d > 0 && l == 2 * d && l_sel == 4 * d &&
+           l_sel == 64 && S_cmp >= 1 && S_cmp <= 64 * 64 && S_sel >= 1 && S_sel <= 2048 && n_top >= 3 && n_top <= 64 && t_token >= 0 &&
+           S_kv >= t_token + 1 && (int64_t)S_kv * 128 < ((int64_t)1 << 31) && kcs % 8 == 0 && kcb % 8 == 0 && kcg % 8 == 0 &&
+           ((uintptr_t)Kc % 16 == 0) && sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, ksb, ksg, kss, vsb, vsg, vss, Q, K, V);
+}
+
+int launch_decode_step(const void *Q, const void *Kc, const void *K, const void *V, void *O, int32_t *ranges_out, int B, int G, int h, int S_cmp,
+                       int S_sel, int S_kv, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss,
+                       int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *ws, size_t ws_bytes, hipStream_t st) {
+    const int64_t R = (int64_t)B * G;
+    NSA_CHECK_ARG(R >= 1 && R <= (1 << 24), "decode step: bad row count");
+    const int nchunk = ((S_cmp + 63) / 64);
+    int nw = 16, ns = 1;
+    NSA_CHECK_ARG(decode_step_plan(R, nchunk, &nw, &ns), "decode step: shape not covered (decode_step_supported)");
+    DecStepParams P{Q, Kc, nullptr, nullptr, nullptr, nullptr, (int)R, G, h, S_cmp, S_sel, ns, nchunk, (nchunk + ns - 1) / ns, t_token, kcb, kcg, kcs, scale * LOG2E};
+    if (ns > 1) {
+        NSA_CHECK_ARG(ws && ws_bytes >= decode_step_workspace(R, h, S_cmp) && ((uintptr_t)ws % 16 == 0), "decode step: workspace too small");
+        P.part_g = (float *)ws;
+        P.halo_g = P.part_g + (size_t)R * h * 64 * 2;
+        P.pg_g = P.halo_g + (size_t)R * 64 * 16;
+        P.cnt = decode_tickets(st, 2 * R);
+        NSA_CHECK_ARG(P.cnt != nullptr, "decode step: could not allocate the arrival tickets");
+    }
+    SelectParams SP{};
+    if (int rc = select_params_sequential(&SP, S_sel, 64, n_top, 1, 2, n_top)) return rc;
+    SP.out = ranges_out;
+    SP.R = R;
+    SP.S = 1;
+    SP.G = G;
+    SP.t0 = t_token;
+    const int c = (S_sel + 63) / 64;
+    const int cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : c <= 16 ? 16 : 32;
+    const DecAttnArgs AT{Q, K, V, O, G, h, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, scale * LOG2E};
+    void (*k)(DecStepParams, SelectParams, int, DecAttnArgs);
+    const bool bf = dtype == NSA_DT_BF16, split = ns > 1;
+#define NSA_DSK(NW_, SP_, HC_) (bf ? decode_step_kernel<__bf16, NW_, SP_, HC_> : decode_step_kernel<_Float16, NW_, SP_, HC_>)
+    if (h == 6) k = nw == 16 ? (split ? NSA_DSK(16, true, 6) : NSA_DSK(16, false, 6)) : (split ? NSA_DSK(8, true, 6) : NSA_DSK(8, false, 6));
+    else k = nw == 16 ? (split ? NSA_DSK(16, true, 0) : NSA_DSK(16, false, 0)) : (split ? NSA_DSK(8, true, 0) : NSA_DSK(8, false, 0));
+#undef NSA_DSK
+    const size_t lds = dstep_lds(nw);
+    NSA_CHECK_ARG(sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)S_sel) <= (size_t)nw * DEC_ATT_TILE, "decode step: S_sel too large");
+    {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
+        static std::mutex mu;
+        static void *raised[16] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        bool done = false;
+        for (void *r : raised) done |= (r == (void *)k);
+        if (!done) {
+            NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (void *&r : raised)
+                if (!r) {
+                    r = (void *)k;
+                    break;
+                }
+        }
+    }
+    const int64_t grid = ns > 1 ? ((R + 7) / 8) * 8 * ns : R;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nw * 64), lds, st, P, SP, cand, AT);
+    NSA_LAUNCH_CHECK("decode_step");
+    return NSA_OK;
+}
+
+}  // namespace nsa
+
+#ifdef NSA_DEC_TS
+extern "C" __attribute__((visibility("default"))) int nsa_debug_read_ts2(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsa::g_ts2), sizeof(long long) * 32);
+}
+#endif

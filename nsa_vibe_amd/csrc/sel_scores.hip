@@ -628,14 +628,7 @@ __global__ __launch_bounds__(1024) void decode_score_select_kernel(DecodeParams 
     }
     // ---- phase 4: selection attention of the row over the ranges just chosen (same workgroup: the 16 waves take the 64-key chunks,
     // partials merged through LDS -- sel_attn_decode.hpp).  The logits / scores in LDS are dead by now: their space holds the V tiles.
-    if constexpr (ATTEND) {
-#ifdef NSA_DEC_TS
-        if (stop == 3) return;
-#endif
-        __syncthreads();
-        DEC_TS(7);
-        if constexpr (KSTEPS == 2) decode_attend_row<T, true>(AT, row, rs, re, (unsigned char *)dsm, qf);
-    }
+    (void)rs, (void)re, (void)AT;  // (the attention of the row is its own launch behind this kernel: the one-launch step is sel_decode_fused.hip)
 }
 
 static size_t decode_fused_lds(int h, int S_cmp, int S_sel) {
@@ -676,12 +669,8 @@ int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int 
     size_t lds = decode_fused_lds(h, S_cmp, S_sel);
     void (*k)(DecodeParams, SelectParams, int, int, DecAttnArgs, int);
     DecAttnArgs AT{};
-    if (attend) {  // the attention of the row runs in the same launch (Dk = Dv = 64 only: checked by the caller)
-        NSA_CHECK_ARG(Dk == 64, "decode scorer: fused attention needs Dk = 64");
-        AT = *attend;
-        lds = lds > (size_t)DEC_ATT_LDS ? lds : (size_t)DEC_ATT_LDS;
-        k = dtype == NSA_DT_BF16 ? decode_score_select_kernel<__bf16, 2, true> : decode_score_select_kernel<_Float16, 2, true>;
-    } else if (dtype == NSA_DT_BF16) k = Dk == 64 ? decode_score_select_kernel<__bf16, 2, false> : decode_score_select_kernel<__bf16, 4, false>;
+    NSA_CHECK_ARG(attend == nullptr, "decode scorer: the attention is not part of this launch any more (sel_decode_fused.hip)");
+    if (dtype == NSA_DT_BF16) k = Dk == 64 ? decode_score_select_kernel<__bf16, 2, false> : decode_score_select_kernel<__bf16, 4, false>;
     else k = Dk == 64 ? decode_score_select_kernel<_Float16, 2, false> : decode_score_select_kernel<_Float16, 4, false>;
     if (lds > 64 * 1024) {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
         static void *raised[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -701,19 +690,11 @@ int launch_decode_score_select(const void *Q, const void *Kc, int B, int G, int 
     return NSA_OK;
 }
 
-int launch_decode_score_select_attend(const void *Q, const void *Kc, const void *K, const void *V, void *O, int B, int G, int h, int Dk, int S_cmp,
-                                      int S_kv, int64_t csb, int64_t csg, int64_t css, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb,
-                                      int64_t vsg, int64_t vss, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals,
-                                      int S_sel, int l_sel, int n_top, int t_token, int dtype, float scale, int32_t *ranges_out, hipStream_t st,
-                                      int stencil) {
-    const DecAttnArgs AT{Q, K, V, O, G, h, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, scale * LOG2E};
-    return launch_decode_score_select(Q, Kc, B, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel, l_sel, n_top, t_token, dtype,
-                                      scale, ranges_out, st, &AT, stencil);
-}
-
 size_t decode_scores_workspace(int64_t R, int h, int S_cmp) {
     const size_t sc = (size_t)(S_cmp > 0 ? S_cmp : 1);
-    return sizeof(float) * (size_t)R * h * (sc + 2 * (size_t)dec_nchunk((int)sc));
+    const size_t three_kernel = sizeof(float) * (size_t)R * h * (sc + 2 * (size_t)dec_nchunk((int)sc));
+    const size_t split_step = decode_step_workspace(R, h, (int)sc);  // the one-launch step with the logits phase split over workgroups
+    return three_kernel > split_step ? three_kernel : split_step;
 }
 
 int launch_decode_scores(const void *Q, const void *Kc, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp, int64_t csb,

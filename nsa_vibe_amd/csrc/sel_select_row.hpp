@@ -23,6 +23,39 @@ struct SelectParams {
     int forced_plain;  // batched: every forced column is kept and used (S > 2 l'), the forced set is {0} + (cblk - force_local, cblk]
 };
 
+// runs of a selected-block bitmap (wd[c] = blocks 64 c .. 64 c + 63, wave uniform) -> token ranges, by all lanes at once: a lane that starts /
+// ends a run takes the run's index from the bits below it and drops the token bound into scr[2 index (+1)]; lane i then holds run i in
+// (my_s, my_e) ([0, 0) beyond the last run).  scr: 128 ints of LDS private to the wave.
+template <int CAND>
+__device__ __forceinline__ void extract_runs_lanes(const unsigned long long (&wd)[CAND], const int l_sel, const int t, int *scr, int &my_s, int &my_e) {
+    const int lane = lane_id();
+    my_s = 0;
+    my_e = 0;
+        int n_s = 0, n_e = 0;  // runs started / ended in the words so far (wave uniform)
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            const unsigned long long w = wd[c];
+            if (w == 0ull) continue;
+            const unsigned long long below = c > 0 ? (wd[c > 0 ? c - 1 : 0] >> 63) : 0ull;             // block 64c - 1 selected
+            const unsigned long long above = c + 1 < CAND ? (wd[c + 1 < CAND ? c + 1 : c] << 63) : 0ull;  // block 64c + 64 selected
+            const unsigned long long sm = w & ~((w << 1) | below);  // blocks that start a run
+            const unsigned long long em = w & ~((w >> 1) | above);  // blocks that end one
+            const int blk = 64 * c + lane;
+            // (the scalar masks predicate the lanes directly; the run counts so far enter the bit counts as their start value)
+            if (__builtin_amdgcn_inverse_ballot_w64(sm))
+                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, (unsigned)n_s))] = blk * l_sel;
+            if (__builtin_amdgcn_inverse_ballot_w64(em))
+                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, (unsigned)n_e)) + 1] =
+                    min((blk + 1) * l_sel, t + 1);
+            n_s += __popcll(sm);
+            n_e += __popcll(em);
+        }
+        if (lane < n_s) {  // the i-th start pairs with the i-th end: runs are disjoint and ascending
+            my_s = scr[2 * lane];
+            my_e = scr[2 * lane + 1];
+        }
+}
+
 // one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS).  Lane i < min(W, 64) returns
 // range i in (my_s, my_e); ranges beyond the emitted runs are [0, 0).
 // scr: 128 ints of LDS private to the wave, or null.  With it the runs of the selected bitmap are extracted by all lanes at once (a lane
@@ -30,9 +63,11 @@ struct SelectParams {
 // scalar loop walks the runs (about 30 dependent scalar instructions per run: 1.5 us of a decode step).
 // SORT_ALL: keep the per-lane sorted copy also beyond 16 candidates per lane (the select kernel has the registers for it; the fused
 // kernels, at 1024 threads or 250 VGPRs, do not)
+// blk_list (LDS, >= n_top + 3 ints, wave private until the caller publishes it) / nblk: the selected blocks themselves, ascending, and
+// their count -- what a consumer that walks blocks (the fused decode step) needs, before and independent of the run extraction.
 template <int CAND, bool SORT_ALL = false>
 __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, const float *p, const int t, int &my_s, int &my_e,
-                                                     int *scr = nullptr) {
+                                                     int *scr = nullptr, int *blk_list = nullptr, int *nblk = nullptr) {
     const int lane = lane_id();
     const int l_sel = P.l_sel, S_sel = P.S_sel;
     const int sh = P.l_sel_shift;
@@ -222,29 +257,19 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
         unsigned long long wd[CAND];
 #pragma unroll
         for (int c = 0; c < CAND; ++c) wd[c] = __ballot((selbits >> c) & 1u);
-        int n_s = 0, n_e = 0;  // runs started / ended in the words so far (wave uniform)
+        if (blk_list) {  // the picked blocks in ascending order: a set lane drops its block id at the number of set bits below it
+            int nb = 0;
 #pragma unroll
-        for (int c = 0; c < CAND; ++c) {
-            const unsigned long long w = wd[c];
-            if (w == 0ull) continue;
-            const unsigned long long below = c > 0 ? (wd[c > 0 ? c - 1 : 0] >> 63) : 0ull;             // block 64c - 1 selected
-            const unsigned long long above = c + 1 < CAND ? (wd[c + 1 < CAND ? c + 1 : c] << 63) : 0ull;  // block 64c + 64 selected
-            const unsigned long long sm = w & ~((w << 1) | below);  // blocks that start a run
-            const unsigned long long em = w & ~((w >> 1) | above);  // blocks that end one
-            const int blk = 64 * c + lane;
-            // (the scalar masks predicate the lanes directly; the run counts so far enter the bit counts as their start value)
-            if (__builtin_amdgcn_inverse_ballot_w64(sm))
-                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, (unsigned)n_s))] = blk * l_sel;
-            if (__builtin_amdgcn_inverse_ballot_w64(em))
-                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, (unsigned)n_e)) + 1] =
-                    min((blk + 1) * l_sel, t + 1);
-            n_s += __popcll(sm);
-            n_e += __popcll(em);
+            for (int c = 0; c < CAND; ++c) {
+                const unsigned long long w = wd[c];
+                if (w == 0ull) continue;
+                if (__builtin_amdgcn_inverse_ballot_w64(w))
+                    blk_list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(w >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)w, (unsigned)nb))] = 64 * c + lane;
+                nb += __popcll(w);
+            }
+            *nblk = nb;
         }
-        if (lane < n_s) {  // the i-th start pairs with the i-th end: runs are disjoint and ascending
-            my_s = scr[2 * lane];
-            my_e = scr[2 * lane + 1];
-        }
+        extract_runs_lanes<CAND>(wd, l_sel, t, scr, my_s, my_e);
         return;
     }
     int nrun = 0;

@@ -639,3 +639,117 @@ def test_scorer_64bit_output_offsets(nv, orc):
     rs = ss._select(rows, len(ts) * G, 1, G, 0, t_rows, m, n, True, 2, 0, 1, n).cpu().numpy()
     want = orc.select_topn_ranges_rows(rows.cpu().numpy(), np.repeat(ts, G), om, n, True, 2)
     assert norm(rs) == norm(want)
+
+
+@pytest.mark.parametrize("S_ctx,B", [(64, 2), (700, 3), (1041, 2), (4096, 5), (16384, 3), (40000, 2), (65536, 2)])
+def test_decode_step_kernel_forms_agree(nv, orc, tune, S_ctx, B):
+    """the one-launch decode step (sel_decode_fused.hip) in every form -- 16 / 8 waves per row, the logits phase of a row on one
+    workgroup or split over 2 / 4 / 16 (the last arriver finishes the row) -- against the three separate launches (DECODE_UNFUSED = 1)
+    and the round-2 kernels (DECODE_STEP = 0): ranges bit-identical everywhere, O bit-identical wherever the gather uses the same
+    number of waves (the partial records of a row are merged in wave order); and the ranges against the oracle's selector on the
+    device scores, O against the oracle's attention.  Reference path: nsa/core/nsa_attention.py:651-672, 704-830."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S_ctx * 7 + B)
+    G, h, D, n = 2, 6, 64, 16
+    meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mo = orc.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).bfloat16()  # noqa: E731
+    Q, Kc = mk(B, 1, G, h, D), mk(B, G, max(meta.S_cmp, 1), D)[:, :, : meta.S_cmp]
+    K, V = mk(B, G, S_ctx + 5, D)[:, :, :S_ctx], mk(B, G, S_ctx + 5, D)[:, :, :S_ctx]  # views of a longer cache
+    t = S_ctx - 1
+    outs = {}
+    for nw in (16, 8):
+        tune("DECODE_WAVES", nw)
+        tune("DECODE_STEP", 1), tune("DECODE_UNFUSED", 1)
+        outs[(nw, "three launches")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        tune("DECODE_UNFUSED", -1)
+        for ns in (-1, 1, 2, 4, 16):
+            tune("DECODE_SPLIT", ns)
+            outs[(nw, f"step, split {ns}")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+            outs[(nw, f"step, split {ns}, again")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)  # tickets left clean, run-to-run bits
+        tune("DECODE_SPLIT", -1)
+        tune("DECODE_STEP", 0)
+        outs[(nw, "round-2 kernels")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    torch.cuda.synchronize()
+    O_ref, r_ref = outs[(16, "three launches")]
+    for (nw, tag), (O, r) in outs.items():
+        assert torch.equal(r, r_ref), (nw, tag)
+        assert torch.equal(O, outs[(nw, "three launches")][0]), (nw, tag)
+        assert (O.float() - O_ref.float()).abs().max().item() <= 1e-2
+    p = nv.selection_scores(Q, Kc, meta)
+    want = orc.select_topn_ranges(p[:, 0].cpu().numpy(), mo, n, t)
+    assert norm(r_ref.cpu().numpy()) == norm(want)
+    f = lambda a: a.float().cpu().numpy()  # noqa: E731
+    O_or = orc.sel_attention_masked(f(Q), f(K), f(V), r_ref.cpu().numpy()[:, None])
+    assert np.abs(f(O_ref) - O_or).max() <= 1e-2
+
+
+@pytest.mark.parametrize("h", [1, 3, 4, 8, 16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_decode_step_kernel_other_group_sizes(nv, tune, h, dtype):
+    """the one-launch decode step with h != 6 heads per group (the head sum of Eq.10 takes its generic form: columns >= h enter as zeros)
+    and f16 inputs, unsplit and split, against the three separate launches: ranges and O bit-identical"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(50 + h)
+    B, G, D, n, S_ctx = 3, 2, 64, 16, 9000
+    meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).to(dtype)  # noqa: E731
+    Q, Kc, K, V = mk(B, 1, G, h, D), mk(B, G, meta.S_cmp, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)
+    t = S_ctx - 1
+    tune("DECODE_UNFUSED", 1)
+    O0, r0 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    tune("DECODE_UNFUSED", -1)
+    for ns in (1, 4):
+        tune("DECODE_SPLIT", ns)
+        O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1) and torch.equal(O0, O1), (h, ns)
+
+
+@pytest.mark.parametrize("S_ctx", [3000, 16384, 65536])
+def test_decode_step_on_tie_heavy_scores(nv, orc, tune, S_ctx):
+    """the one-launch decode step (scores in registers, selector fed from LDS, block list -> gather) against the three separate launches
+    (DECODE_UNFUSED = 1) and the oracle's selector, on score rows full of exact ties: K_cmp = 0 (every compressed
+    column has the same probability: interior blocks tie, the tie order 'lower index first' decides all 13 picks), K_cmp built from 3
+    distinct rows (plateaus), a peaked softmax (most blocks exactly 0), and NaN logits in one sequence (no candidates: forced blocks only).
+    The reference order (key desc, index asc): nsa/core/selection_scorer.py:182-187; PRD.md:46."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S_ctx)
+    B, G, h, D, n = 5, 2, 6, 64, 16
+    meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mo = orc.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).bfloat16()  # noqa: E731
+    Q, K, V = mk(B, 1, G, h, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)
+    Kc = torch.zeros(B, G, meta.S_cmp, D, device="cuda", dtype=torch.bfloat16)  # b = 0: all ties
+    three = mk(3, D)
+    Kc[1] = three[torch.randint(0, 3, (G, meta.S_cmp), device="cuda", generator=g)]  # plateaus
+    Kc[2] = mk(G, meta.S_cmp, D)
+    Kc[2, :, 777 % meta.S_cmp] = Q[2, 0, :, 0] * 40  # one column takes all the mass: the other blocks' scores underflow to exact zeros
+    Kc[3] = mk(G, meta.S_cmp, D)  # ordinary
+    Kc[4] = mk(G, meta.S_cmp, D)
+    Kc[4, 0, 5] = float("nan")  # one NaN logit poisons the row's normaliser: every score NaN, no candidate
+    t = S_ctx - 1
+    tune("DECODE_UNFUSED", 1)
+    O0, r0 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    tune("DECODE_UNFUSED", -1)
+    for nw in (16, 8):
+        tune("DECODE_WAVES", nw)
+        for ns in (-1, 1, 4):
+            tune("DECODE_SPLIT", ns)
+            O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+            torch.cuda.synchronize()
+            assert torch.equal(r0, r1), (nw, ns)
+    tune("DECODE_WAVES", -1), tune("DECODE_SPLIT", -1)
+    O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    fin = torch.isfinite(O0.float()).all(dim=-1).all(dim=-1)
+    assert torch.equal(O0[fin], O1[fin])
+    # against the oracle's selector on the device scores (rows whose scores are NaN: compared among the kernels above only)
+    p = nv.selection_scores(Q, Kc, meta)[:, 0].cpu().numpy()
+    ok = np.isfinite(p).all(axis=-1)
+    want = orc.select_topn_ranges(np.where(ok[..., None], p, 0.0).astype(np.float32), mo, n, t)
+    got = r1.cpu().numpy()
+    for b in range(B):
+        for gg in range(G):
+            if ok[b, gg]:
+                assert norm(got[b, gg][None]) == norm(want[b, gg][None]), (b, gg)
+    assert got[0, 0].tolist()[:3] == [[0, 64 * 14], [64 * (t // 64 - 1), t + 1], [0, 0]] or S_ctx < 64 * 16  # all ties: blocks 1..13 win
