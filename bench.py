@@ -125,6 +125,45 @@ def gathered_tiles(ranges, S_kv, tpw=BLK_ROWS, keys=BLK_KEYS):
     return total
 
 
+def attention_extremes(nv, device, iters=5):
+    """SURVEY 8(d)'s two synthetic extremes for the selection-attention kernel (the reference's bench/bench_sel_triton.py:13-34): every row
+    takes (a) ONE span [0, L) and (b) n equal spans, the same ones for all rows -- the rows of a wave share every K/V block they touch, the
+    opposite corner from the selector's random picks (where at 64k a block serves one row of a wave and 6 of 16 MFMA columns).  What the
+    kernel reaches here is its own MFMA ceiling; what the headline shape lacks relative to it is the workload's sparsity structure."""
+    out = {}
+    S_kv, L = 65536, N_SEL * L_SEL
+    for B_, S_ in ((4, 16384), (16, 4096)):
+        g = torch.Generator(device=device)
+        g.manual_seed(5)
+        Q = torch.randn(B_, S_, G, H, D, device=device, generator=g).bfloat16()
+        K = torch.randn(B_, G, S_kv, D, device=device, generator=g).bfloat16()
+        V = torch.randn(B_, G, S_kv, D, device=device, generator=g).bfloat16()
+        cases = {}
+        one = torch.zeros(B_, S_, G, N_SEL, 2, dtype=torch.int32, device=device)
+        one[..., 0, 1] = L
+        cases["single_span_0_1024"] = one
+        eq = torch.zeros(B_, S_, G, N_SEL, 2, dtype=torch.int32, device=device)
+        starts = torch.arange(N_SEL, device=device, dtype=torch.int32) * (S_kv // N_SEL)
+        eq[..., 0] = starts
+        eq[..., 1] = starts + L_SEL
+        cases["16_equal_spans_of_64_same_for_all_rows"] = eq
+        rnd = torch.zeros(B_, S_, G, N_SEL, 2, dtype=torch.int32, device=device)  # for contrast: 16 random blocks per row, no sharing
+        blk = torch.rand(B_, S_, G, S_kv // L_SEL, device=device, generator=g).topk(N_SEL, dim=-1).indices.sort(dim=-1).values.int()
+        rnd[..., 0] = blk * L_SEL
+        rnd[..., 1] = blk * L_SEL + L_SEL
+        cases["16_random_blocks_per_row_no_sharing"] = rnd
+        for name, rg in cases.items():
+            with torch.no_grad():
+                ms = time_events(lambda: nv.selection_attention_hip(Q, K, V, rg), iters)
+            fl = 4.0 * H * L * D * B_ * S_ * G
+            tf = fl / (ms * 1e-3) / 1e12
+            out[f"{name}_B{B_}_S{S_}"] = {"ms": ms, "rows": B_ * S_ * G, "keys_per_row": L, "tflops": tf, "attn_mfma_frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                                          "qk_frac": 0.5 * tf / MFMA_BF16_PEAK_TFLOPS}
+        del Q, K, V, cases, one, eq, rnd, blk
+        torch.cuda.empty_cache()
+    return out
+
+
 def decode_bench(nv, B, S_ctx, steps, device):
     """Decode-shaped hot path: B sequences at context S_ctx, one new token each (sequential-mode selector,
     preallocated K/V cache passed as a strided view -- no torch.cat append as in nsa/cache/kv_cache.py:28-30).
@@ -732,6 +771,7 @@ def main():
                     if S2 == 4096 and B2 == 8:
                         extra[f"sel_attn_fwd_bwd_S{S2}_B{B2}"] = backward_bench(nv, m2, Q2, K2, V2, S2)
                     del m2, Q2, Kc2, K2, V2
+                extra["attention_extremes"] = attention_extremes(nv, device)
                 # next scope rows: the sliding/compressed branch kernel (MFMA bound), the whole layer on the native path
                 for S2, B2 in ((4096, 8), (16384, 1), (65536, 1)):
                     extra[f"band_S{S2}_B{B2}"] = band_bench(nv, B2, S2, device)

@@ -67,12 +67,73 @@ struct SegChunks {
     }
 };
 
+// ---- which chunks a wave gathers, and in which order.  NW = 8: e = wave, wave + 8, ...  NW = 16 ("edge rule", from 3 chunks on): the first
+// chunk goes to wave 0 and the last two to waves 14 and 15, the chunks between them (p = e - 1) go round the waves in the order
+// 1 .. 13, 0, 14, 15; a wave takes its edge chunk first, then its middle chunks in ascending order.  For selector output the edge chunks
+// are the forced blocks (0, t//l' - 1, t//l'), known from t alone: the fused decode step lets those three waves fetch them at kernel start,
+// behind the whole scoring chain (sel_decode_fused.hip).  A pure function of (e, NC): the standalone launch follows the same rule, so
+// the partial records of a row are merged in the same grouping on both routes.
+template <int NW>
+__device__ __forceinline__ int dec_first_chunk(int w, int NC) {
+    if (NW != 16 || NC < 3) return w < NC ? w : NC;
+    if (w == 0) return 0;
+    if (w == 14) return NC - 2;
+    if (w == 15) return NC - 1;
+    return w <= NC - 3 ? w : NC;  // middle waves 1 .. 13: p = w - 1
+}
+template <int NW>
+__device__ __forceinline__ int dec_next_chunk(int cur, int w, int NC) {
+    if (NW != 16 || NC < 3) return cur + NW;
+    const bool edge = (w == 0 && cur == 0) || (w == 14 && cur == NC - 2) || (w == 15 && cur == NC - 1);
+    const int iw = (w >= 1 && w <= 13) ? w - 1 : (w == 0 ? 13 : w);
+    const int p = edge ? iw : cur - 1 + 16;
+    return p < NC - 3 ? p + 1 : NC;
+}
+
+// a chunk fetched ahead of time (fused decode step): K rows by LDS-DMA into an 8 KiB tile of their own (XOR-swizzled 16-B pieces, the
+// image of sel_attn_blocks_mfma.hip), V rows into the wave's V tile as always.  Needs contiguous K rows (kss = 64).
+struct DecPrefetch {
+    int tok0;                    // first key of the chunk the wave fetched, -1 = none
+    const unsigned char *ktile;  // its K image in LDS
+};
+template <typename T>
+__device__ __forceinline__ void decode_prefetch_chunk(const DecAttnArgs &A, int64_t row, int tok0, int len, unsigned char *vtile, unsigned char *ktile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int lane = lane_id();
+    const int g = (int)(row % A.G);
+    const int64_t b = row / A.G;
+    const uint64_t ka = (uint64_t)((const T *)A.K + b * A.ksb + (int64_t)g * A.ksg), va = (uint64_t)((const T *)A.V + b * A.vsb + (int64_t)g * A.vsg);
+    const uint32_t ka_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ka), ka_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ka >> 32));
+    const uint32_t va_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)va), va_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(va >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane((int)((int64_t)A.S_kv * 128));
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ka_hi << 32) | (uint64_t)ka_lo), (short)0, bytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)va_hi << 32) | (uint64_t)va_lo), (short)0, bytes, 0x00020000);
+    const int ld_row = lane >> 3, ld_piece = lane & 7;
+    const uint32_t ksw = (uint32_t)((ld_piece ^ (ld_row & 7)) << 4);
+    const uint32_t vsw = (uint32_t)(((((ld_piece >> 1) ^ ((ld_row >> 1) & 3)) << 1) | (ld_piece & 1)) << 4);
+    const int so = uniform(tok0 * 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rc = min(8 * i + ld_row, len - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(ktile + i * 1024), 16, rc * 128 + ksw, so, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rc = min(8 * i + ld_row, len - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(vtile + i * 1024), 16, rc * 128 + vsw, so, 0, 0);
+    }
+#else
+    (void)A, (void)row, (void)tok0, (void)len, (void)vtile, (void)ktile;
+#endif
+}
+
 // vt: NW * DEC_ATT_TILE bytes of LDS, 16-byte aligned (V tiles, then the partial records); every thread of the NW * 64-thread workgroup must
 // call (one workgroup barrier inside).  qf_in: the row's Q^T fragments if the caller holds them already (lane (rho, q):
 // Q[head min(rho, h-1)][32 s + 8 q ..], s = 0, 1).  NC chunks; chunks with len <= 0 must not occur.
 template <typename T, int NW, typename CH>
 __device__ __forceinline__ void decode_attend_chunks(const DecAttnArgs &A, int64_t row, const CH &ch, const int NC, unsigned char *vt,
-                                                     const typename MfmaT<T>::x8 *qf_in = nullptr) {
+                                                     const typename MfmaT<T>::x8 *qf_in = nullptr, const DecPrefetch pre = DecPrefetch{-1, nullptr}) {
     using M = MfmaT<T>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
@@ -138,15 +199,24 @@ __device__ __forceinline__ void decode_attend_chunks(const DecAttnArgs &A, int64
     for (int m = 0; m < 4; ++m) o[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun = -INFINITY, lrun = 0.f;
 
-    int cur = wave, tok0 = 0, len = 0;
+    int cur = dec_first_chunk<NW>(wave, NC), tok0 = 0, len = 0;
     x8 kfr[4][2];
     if (cur < NC) {
         ch.get(cur, tok0, len);
-        load_k(tok0, len, kfr);  // K first: loads complete in order, and the scores need K before the P V product needs V
-        issue_v(tok0, len);
+        if (pre.tok0 == tok0 && pre.tok0 >= 0) {
+            // this chunk went out at kernel start (K and V by LDS-DMA): both have long landed; the K fragments come from the LDS image
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) kfr[u][s] = *(const x8 *)(pre.ktile + (16 * u + rho) * ROWB + (((4 * s + q) ^ (rho & 7)) << 4));
+        } else {
+            load_k(tok0, len, kfr);  // K first: loads complete in order, and the scores need K before the P V product needs V
+            issue_v(tok0, len);
+        }
     }
     while (cur < NC) {
-        const int nxt = cur + NW;
+        const int nxt = dec_next_chunk<NW>(cur, wave, NC);
         const bool hn = nxt < NC;
         int ntok0 = 0, nlen = 0;
         [[maybe_unused]] x8 kn[4][2];

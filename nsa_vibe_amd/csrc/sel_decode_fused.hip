@@ -52,21 +52,31 @@ struct DecStepParams {
 
 constexpr int DSTEP_PART = 16 * 64 * 2;  // floats: [head][chunk][2]
 constexpr int DSTEP_HALO = 64 * 16;      // floats: [chunk][head] scaled logit of the chunk's last row
-static size_t dstep_lds(int nw) { return (size_t)nw * DEC_ATT_TILE + sizeof(float) * nw * 16 + sizeof(int) * (128 + 68 + 4); }
+constexpr int DSTEP_TAIL = 1024 + 4 * (128 + 68 + 4);  // bytes behind the V tiles: mlw [16][16] f32 | scr | list | misc
+static size_t dstep_lds(int nw) { return (size_t)nw * DEC_ATT_TILE + DSTEP_TAIL + (nw == 16 ? 3 * DEC_ATT_TILE : 0); }
+
+// workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, NOT for its vector memory operations
+// (__syncthreads() drains vmcnt too, which would stall the three prefetching waves -- and with them the whole workgroup -- until their
+// forced blocks have landed, moving that traffic back onto the critical path)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <typename T, int NW, bool SPLIT, int HC>
 __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT) {
     using M = MfmaT<T>;
     using x8 = typename M::x8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // the score phases live where the V tiles of the gather will be: part | halo | pg
-    float *part = (float *)lds;
+    // the score phases live where the V tiles of the gather will be: part | halo | pg.  PREF (16 waves, unsplit): waves 0, 14 and 15 fetch
+    // the row's forced blocks (0, t//64 - 1, t//64: known from t alone, selection_scorer.py:159-170) at kernel start, V into their own
+    // tiles, K into three tiles behind the tail -- so the score data starts at tile 1
+    constexpr bool PREF = NW == 16 && !SPLIT;
+    float *part = (float *)(lds + (PREF ? DEC_ATT_TILE : 0));
     float *halo = part + DSTEP_PART;
     float *pg = halo + DSTEP_HALO;  // [S_sel]
     float *mlw = (float *)(lds + NW * DEC_ATT_TILE);  // [NW][16] per-wave copy of the per-head log-sum-exp
     int *scr = (int *)(mlw + NW * 16);                // [128] run extraction of the selector
     int *list = scr + 128;                            // [68] picked blocks, ascending
     int *misc = list + 68;                            // [0] number of picked blocks, [1] ticket
+    [[maybe_unused]] unsigned char *ktiles = lds + NW * DEC_ATT_TILE + DSTEP_TAIL;  // PREF: [3] K images of the prefetched blocks
 
     const int lane = lane_id(), wave = uniform((int)(threadIdx.x >> 6)), rho = lane & 15, q = lane >> 4;
     const int h = P.h;
@@ -82,7 +92,6 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     const int g = row % P.G;
     const int64_t b = row / P.G;
     const int hc = min(rho, h - 1);  // head of this lane's column (columns >= h repeat the last head: their results are never used)
-
     // ---- phase 1: logits of this workgroup's chunks (64 compressed rows each = MFMA rows; heads = columns), up to two per wave,
     // all loads out at once
     x8 qf[2];
@@ -105,6 +114,19 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
             }
         }
     }
+    // (behind the K_cmp loads in program order: vector memory operations complete in order, the scores must not wait for these)
+    DecPrefetch pre{-1, nullptr};
+    if constexpr (PREF) {
+        const int cb = P.t_token >> 6, t_end = min(P.t_token + 1, AT.S_kv);
+        const int slot = wave == 0 ? 0 : wave - 13;  // waves 14, 15 -> K tiles 1, 2
+        if ((wave == 0 || wave >= 14) && cb >= 2 && cb < P.S_sel && AT.kss == 64) {
+            const int blk = wave == 0 ? 0 : cb - (15 - wave);
+            pre.tok0 = 64 * blk;
+            pre.ktile = ktiles + slot * DEC_ATT_TILE;
+            decode_prefetch_chunk<T>(AT, row, pre.tok0, min(64, t_end - pre.tok0), lds + wave * DEC_ATT_TILE, ktiles + slot * DEC_ATT_TILE);
+        }
+    }
+
     for (int i = threadIdx.x; i < P.S_sel; i += NW * 64) pg[i] = 0.f;  // blocks without a compressed row keep a zero score
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
         __syncthreads();
         DS_TS(4);
     } else {
-        __syncthreads();
+        lds_barrier();
         DS_TS(4);
     }
 
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
             pg[j] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.pg_g + (int64_t)row * 2048 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     DS_TS(6);
-    __syncthreads();
+    lds_barrier();
     DS_TS(7);
 
     // ---- phase 3: top-n + forced blocks (one wave); the picked blocks go to LDS for the gather, the merged ranges to the caller.
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
         if (lane == 0) misc[0] = nb;
     }
     DS_TS(8);
-    __syncthreads();  // the scores are dead from here on: their space holds the V tiles
+    lds_barrier();  // the scores are dead from here on: their space holds the V tiles
     if (wave == 0 && lane < SP.W) {
         int32_t *out = SP.out + (int64_t)row * SP.W * 2;
         out[2 * lane] = rs;
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     // ---- phase 4: selection attention over the picked blocks (wave e mod NW gathers block e; partials merged through LDS)
     const ListChunks ch{list, min(P.t_token + 1, AT.S_kv)};
     DS_TS(9);
-    decode_attend_chunks<T, NW>(AT, row, ch, NC, lds, qf);
+    decode_attend_chunks<T, NW>(AT, row, ch, NC, lds, qf, pre);
     DS_TS(10);
 }
 
@@ -443,7 +465,7 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     else k = nw == 16 ? (split ? NSA_DSK(16, true, 0) : NSA_DSK(16, false, 0)) : (split ? NSA_DSK(8, true, 0) : NSA_DSK(8, false, 0));
 #undef NSA_DSK
     const size_t lds = dstep_lds(nw);
-    NSA_CHECK_ARG(sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)S_sel) <= (size_t)nw * DEC_ATT_TILE, "decode step: S_sel too large");
+    NSA_CHECK_ARG(sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)S_sel) <= 3 * (size_t)DEC_ATT_TILE, "decode step: S_sel too large");
     {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
         static std::mutex mu;
         static void *raised[16] = {};
