@@ -381,7 +381,7 @@ def cpu_baseline(S, B, seed=3, min_seconds=10.0):
 def pmc_traffic(tag, key="traffic_bytes"):
     """HBM bytes per launch for a workload, measured with rocprofv3 PMC counters in separate passes (tools/pmc_traffic.sh) and
     committed under profiles/ (bench.py cannot run the profiler on itself); None if not measured."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             return float(json.load(open(os.path.join(ROOT, "profiles", rnd, f"traffic_{tag}.json")))[key])
         except (OSError, KeyError, ValueError, TypeError):
@@ -719,7 +719,7 @@ def main():
             hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                    "frac_of_measured_stream_rate": ach / 6290.0, "traffic": traffic,
                    "note": "HBM-side bytes of the attention launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per the MI355X guide, "
-                           "profiles/r02/traffic_*.json, same shape) / HIP-event time"}
+                           "profiles/r03/traffic_*.json, same shape) / HIP-event time"}
         # what binds: the larger of the two memory-side fractions.  With the plain walk the 64k launch ran at 94 % of the rate a streaming
         # copy reaches (115.6 GB of L2 misses: a (b,g)'s K/V is 16 MiB against 4 MiB of L2 per XCD); the key-split form (two key halves on
         # different XCDs) cut the misses to 45 GB, and the launch now sits nearer to the L2 / L1->LDS path (the gathered blocks) than to HBM.

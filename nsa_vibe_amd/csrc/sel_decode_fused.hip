@@ -412,7 +412,9 @@ static bool decode_step_plan(int64_t R, int nchunk, int *nw_out, int *ns_out) {
         const int ns1 = (nchunk + nw - 1) / nw;  // one chunk per wave
         if (ns1 > ns && R * ns1 <= slots) ns = ns1;
         // few rows: spread the K_cmp sweep over more CUs (one CU pulls ~30 GB/s from memory whatever its waves do: MI355X guide, gather table)
-        while (ns < 16 && R * ns * 2 <= slots / 2 && (nchunk + ns * 2 - 1) / (ns * 2) >= 2) ns *= 2;
+        // -- while every workgroup keeps at least 8 chunks (64 KiB): the two hand-offs of the team form cost ~2.5 us, a 4k context (4 chunks)
+        // is faster on one workgroup
+        while (ns < 16 && R * ns * 2 <= slots / 2 && (nchunk + ns * 2 - 1) / (ns * 2) >= 8) ns *= 2;
     }
     *nw_out = nw;
     *ns_out = ns;

@@ -77,16 +77,18 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     using mask_t = typename std::conditional<(CAND <= 32), unsigned, unsigned long long>::type;
     float key[CAND];
     mask_t selbits = 0;  // bit c = block lane + 64 c selected
-    // a slot (64 blocks) that lies below the valid bound is one unpredicated load at an immediate offset from p + lane; only the slot
-    // the bound falls into is predicated per lane, and slots above it are not read at all (with causal_skip the scorer never wrote them)
-    const float *pl = p + lane;
+    // ALL slot loads go out before the first key is formed: unconditional, the index clamped to the last valid block (an entry the scorer
+    // has written even with causal_skip; a row without any valid block reads entry 0 and masks it).  The first form guarded every slot with
+    // a scalar branch -- no load crossed a branch, so a row paid one dependent memory round trip PER SLOT (8 on average at 64k): the
+    // select kernel ran at the latency of ~8 serial HBM reads per row, 57 % of its wave cycles waiting (profiles/r02/pmc_select_S65536_B1.txt).
+    const int jmax = max(nvalid_blocks - 1, 0);
+    float vraw[CAND];
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) vraw[c] = p[min(lane + 64 * c, jmax)];
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
         const int j = lane + 64 * c;
-        float v = 0.f;
-        if (64 * c + 64 <= nvalid_blocks) v = pl[64 * c];
-        else if (64 * c < nvalid_blocks && j < nvalid_blocks) v = pl[64 * c];
-        const float k = __fsub_rn(v, __fmul_rn((float)j, 1e-8f));
+        const float k = __fsub_rn(vraw[c], __fmul_rn((float)j, 1e-8f));
         key[c] = j < nvalid_blocks ? k : -INFINITY;
     }
     if (P.all_valid) {
