@@ -52,6 +52,7 @@ enum Tune {
     TUNE_DECODE_WAVES,      // NSA_HIP_DECODE_WAVES: waves per row workgroup of the decode kernels, -1 by the number of rows, 8 or 16
     TUNE_DECODE_SPLIT,      // NSA_HIP_DECODE_SPLIT: fused decode step, workgroups that share the logits phase of one row, -1 by shape, N forces N
     TUNE_DECODE_STEP,       // NSA_HIP_DECODE_STEP: 1 = the one-launch decode step of sel_decode_fused.hip wherever it applies (default), 0 = the round-2 kernels
+    TUNE_DECODE_TEAM_SPIN,  // NSA_HIP_DECODE_TEAM_SPIN: split decode step, polls a workgroup waits for its team before it goes on alone; -1 = 512, 0 = never waits
     TUNE_COUNT
 };
 int tuning(Tune t);

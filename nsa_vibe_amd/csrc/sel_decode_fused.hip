@@ -45,7 +45,7 @@ struct DecStepParams {
     float *halo_g;   // SPLIT: [R][64][16] scaled logit of every chunk's last row, per head
     float *pg_g;     // SPLIT: [R][2048] group scores of the row's blocks
     int *cnt;        // SPLIT: [2][R] arrivals (records published) and tickets (scores published); zero between launches
-    int R, G, h, S_cmp, S_sel, NS, nchunk, cpg, t_token;
+    int R, G, h, S_cmp, S_sel, NS, nchunk, cpg, t_token, spin;
     int64_t csb, csg, css;
     float c2;
 };
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     float *mlw = (float *)(lds + NW * DEC_ATT_TILE);  // [NW][16] per-wave copy of the per-head log-sum-exp
     int *scr = (int *)(mlw + NW * 16);                // [128] run extraction of the selector
     int *list = scr + 128;                            // [68] picked blocks, ascending
-    int *misc = list + 68;                            // [0] number of picked blocks, [1] ticket
+    int *misc = list + 68;                            // [0] number of picked blocks, [1] ticket, [2] team assembled
     [[maybe_unused]] unsigned char *ktiles = lds + NW * DEC_ATT_TILE + DSTEP_TAIL;  // PREF: [3] K images of the prefetched blocks
 
     const int lane = lane_id(), wave = uniform((int)(threadIdx.x >> 6)), rho = lane & 15, q = lane >> 4;
@@ -182,32 +182,76 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
         // s_sleep; the others wait at the barrier it then joins).  The logits themselves never leave the registers: with the row's
         // log-sum-exp every workgroup scores its OWN blocks.  (First form of this kernel: the last arriver re-read all logits from the
         // workspace -- 98 KB per row at 64k, 3.3 us at the ~30 GB/s one CU pulls from memory, and scored all 64 chunks alone.)
-        // The wait needs the row's workgroups resident together: the host launches this form only while R NS workgroups fit the chip at
-        // once, and the poll is bounded (a trap, not a hang, should that ever not hold).
+        // The wait pays off while the row's workgroups are resident together: the host launches this form only while R NS workgroups fit
+        // the chip at once.  It is bounded (P.spin polls), and a workgroup whose team does not assemble in time does the missing work itself
+        // (below): no workgroup ever depends on another one being scheduled.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DS_TS(2);
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(P.cnt + row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int it = 0; __hip_atomic_load(P.cnt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.NS; ++it) {
+            int it = 0;
+            while (__hip_atomic_load(P.cnt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.NS && it < P.spin) {
                 __builtin_amdgcn_s_sleep(2);
-                if (it > (1 << 22)) __builtin_trap();
+                ++it;
             }
+            misc[2] = __hip_atomic_load(P.cnt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.NS ? 1 : 0;
         }
         __syncthreads();
         DS_TS(3);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the compiler from moving the loads below above this point)
-        // the row's records and edge logits -> LDS, one sc1 load per thread
-        for (int i = threadIdx.x; i < h * 64; i += NW * 64) {
-            const int hh = i >> 6, idx = i & 63;
-            if (idx < P.nchunk) {
-                const unsigned long long r = __hip_atomic_load((const unsigned long long *)(P.part_g + (((int64_t)row * h + hh) * 64 + idx) * 2), __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                *(f32x2 *)(part + (hh * 64 + idx) * 2) = (f32x2){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
+        if (misc[2]) {
+            // the row's records and edge logits -> LDS, one sc1 load per thread
+            for (int i = threadIdx.x; i < h * 64; i += NW * 64) {
+                const int hh = i >> 6, idx = i & 63;
+                if (idx < P.nchunk) {
+                    const unsigned long long r = __hip_atomic_load((const unsigned long long *)(P.part_g + (((int64_t)row * h + hh) * 64 + idx) * 2), __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    *(f32x2 *)(part + (hh * 64 + idx) * 2) = (f32x2){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
+                }
+            }
+            for (int i = threadIdx.x; i < P.nchunk * 16; i += NW * 64)
+                if ((i & 15) < h) halo[i] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.halo_g + (int64_t)row * 64 * 16 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else {
+            // The team did not assemble within the poll budget (its other workgroups are not resident yet: a second stream or process holds
+            // the CUs).  Nobody waits for anybody here: this workgroup forms the records and edge logits of ALL chunks of the row itself --
+            // the same instructions on the same data, so the same bits as its team mates publish -- and carries on.  Slower, never stuck.
+            for (int c = wave; c < P.nchunk; c += NW) {
+                x8 b2[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = min(c * 64 + 16 * u + rho, P.S_cmp - 1);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) b2[u][s2] = *(const x8 *)(kb + (int64_t)r * P.css + 32 * s2 + 8 * q);
+                }
+                f32x4 z[4];
+                float m = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    z[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) z[u] = M::mma(b2[u][s2], qf[s2], z[u]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = z[u][j] * P.c2;
+                        z[u][j] = v;
+                        if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) m = fmaxf(m, v);
+                    }
+                }
+                m = xor32_max(xor16_max(m));
+                float l = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(z[u][j] - m);
+                l = xor32_add(xor16_add(l));
+                if (rho < h) {
+                    if (q == 0) *(f32x2 *)(part + (rho * 64 + c) * 2) = (f32x2){m, l};
+                    if (q == 3) halo[c * 16 + rho] = z[3][3];
+                }
             }
         }
-        for (int i = threadIdx.x; i < P.nchunk * 16; i += NW * 64)
-            if ((i & 15) < h) halo[i] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.halo_g + (int64_t)row * 64 * 16 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         __syncthreads();
         DS_TS(4);
     } else {
@@ -441,7 +485,8 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     const int nchunk = ((S_cmp + 63) / 64);
     int nw = 16, ns = 1;
     NSA_CHECK_ARG(decode_step_plan(R, nchunk, &nw, &ns), "decode step: shape not covered (decode_step_supported)");
-    DecStepParams P{Q, Kc, nullptr, nullptr, nullptr, nullptr, (int)R, G, h, S_cmp, S_sel, ns, nchunk, (nchunk + ns - 1) / ns, t_token, kcb, kcg, kcs, scale * LOG2E};
+    DecStepParams P{Q, Kc, nullptr, nullptr, nullptr, nullptr, (int)R, G, h, S_cmp, S_sel, ns, nchunk, (nchunk + ns - 1) / ns, t_token, 0, kcb, kcg, kcs, scale * LOG2E};
+    P.spin = tuning(TUNE_DECODE_TEAM_SPIN) >= 0 ? tuning(TUNE_DECODE_TEAM_SPIN) : 512;  // polls of ~0.5-1 us each before a workgroup goes on alone
     if (ns > 1) {
         NSA_CHECK_ARG(ws && ws_bytes >= decode_step_workspace(R, h, S_cmp) && ((uintptr_t)ws % 16 == 0), "decode step: workspace too small");
         P.part_g = (float *)ws;

@@ -753,3 +753,33 @@ def test_decode_step_on_tie_heavy_scores(nv, orc, tune, S_ctx):
             if ok[b, gg]:
                 assert norm(got[b, gg][None]) == norm(want[b, gg][None]), (b, gg)
     assert got[0, 0].tolist()[:3] == [[0, 64 * 14], [64 * (t // 64 - 1), t + 1], [0, 0]] or S_ctx < 64 * 16  # all ties: blocks 1..13 win
+
+
+@pytest.mark.parametrize("S_ctx,B", [(16384, 2), (65536, 3)])
+def test_decode_step_team_that_never_assembles(nv, tune, S_ctx, B):
+    """split decode step with a poll budget of zero (DECODE_TEAM_SPIN = 0): every workgroup finds its team incomplete and forms the records of
+    the whole row itself -- the path that keeps a workgroup from ever depending on another one being scheduled (two streams or processes
+    sharing the CUs).  Same instructions on the same data: ranges and O bit-identical to the assembled team and to the three launches."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S_ctx + B)
+    G, h, D, n = 2, 6, 64, 16
+    meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).bfloat16()  # noqa: E731
+    Q, Kc, K, V = mk(B, 1, G, h, D), mk(B, G, meta.S_cmp, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)
+    t = S_ctx - 1
+    tune("DECODE_UNFUSED", 1)
+    O0, r0 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    tune("DECODE_UNFUSED", -1)
+    for nw in (16, 8):
+        tune("DECODE_WAVES", nw)
+        for ns in (2, 4, 16):
+            tune("DECODE_SPLIT", ns)
+            for spin in (0, -1):
+                tune("DECODE_TEAM_SPIN", spin)
+                O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+                O2, r2 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)  # the tickets were left clean
+                torch.cuda.synchronize()
+                assert torch.equal(r0, r1) and torch.equal(r0, r2), (nw, ns, spin)
+                assert torch.equal(O1, O2), (nw, ns, spin)
+                if nw == 16:
+                    assert torch.equal(O0, O1), (nw, ns, spin)
