@@ -239,3 +239,46 @@ def test_fuzz_training_gradients_native_vs_eager(seed, monkeypatch):
     for a, e in zip(grads["native"], grads["eager"]):
         assert torch.isfinite(a).all(), cfg
         assert (a - e).abs().max().item() <= 2e-3 * max(1.0, e.abs().max().item()), cfg
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_decode_step(nv, orc, seed, tune):
+    """the one-launch decode step over random shapes -- contexts from a few tokens to 20k (t not a multiple of anything, caches longer
+    than the context, contexts before the first compressed token / the first complete block / the third block, where the forced blocks
+    collapse and nothing is fetched ahead), 1..16 heads per group, 3..24 ranges per row, up to 48 rows, 16 / 8 waves, split or not --
+    against the three separate launches (ranges and O bit-identical) and the oracle (selector on the device scores; attention)."""
+    rng = np.random.default_rng(9000 + seed)
+    dtype = [torch.bfloat16, torch.float16][seed % 2]
+    B, G = int(rng.integers(1, 13)), int(rng.choice([1, 2, 4]))
+    h = int(rng.choice([1, 2, 3, 4, 6, 6, 6, 8, 12, 16]))
+    n = int(rng.choice([3, 4, 8, 16, 16, 16, 24]))
+    t = int(rng.choice([int(rng.integers(0, 64)), int(rng.integers(64, 200)), int(rng.integers(200, 3000)), int(rng.integers(3000, 20000))]))
+    S_ctx = t + 1 + int(rng.integers(0, 70))  # the cache may hold more tokens than the step may see
+    D = 64
+    meta = nv.build_block_meta(t + 1, 32, 16, 64, n, 512)
+    mo = orc.build_block_meta(t + 1, 32, 16, 64, n, 512)
+    Q = rng.standard_normal((B, 1, G, h, D), dtype=np.float32)
+    Kc = rng.standard_normal((B, G, max(meta.S_cmp, 1), D), dtype=np.float32)[:, :, : meta.S_cmp]
+    K = rng.standard_normal((B, G, S_ctx, D), dtype=np.float32)
+    V = rng.standard_normal((B, G, S_ctx, D), dtype=np.float32)
+    Qd, Kcd, Kd, Vd = dev(Q, dtype), dev(Kc, dtype), dev(K, dtype), dev(V, dtype)
+    tune("DECODE_UNFUSED", 1)
+    tune("DECODE_WAVES", int(rng.choice([-1, 8, 16])))
+    O0, r0 = nv.selection_decode_step(Qd, Kcd, Kd, Vd, meta, n, t)
+    tune("DECODE_UNFUSED", -1)
+    tune("DECODE_SPLIT", int(rng.choice([-1, 1, 2, 4, 16])))
+    tune("DECODE_TEAM_SPIN", int(rng.choice([-1, -1, 0])))
+    O1, r1 = nv.selection_decode_step(Qd, Kcd, Kd, Vd, meta, n, t)
+    torch.cuda.synchronize()
+    assert torch.equal(r0, r1) and torch.equal(O0, O1), (B, G, h, n, t)
+    if meta.S_cmp > 0:
+        p = nv.selection_scores(Qd, Kcd, meta)[:, 0].cpu().numpy()
+    else:
+        p = np.zeros((B, G, meta.S_sel), np.float32)
+    assert norm_ranges(r1.cpu().numpy()) == norm_ranges(orc.select_topn_ranges(p, mo, n, t)), (B, G, h, n, t)
+    ref = orc.sel_attention_masked(rounded(Q, dtype), rounded(K, dtype), rounded(V, dtype), r1.cpu().numpy()[:, None])
+    assert np.abs(O1.float().cpu().numpy() - ref).max() <= _bound(ref, dtype)
+
+
+def norm_ranges(r):
+    return [[(int(s), int(e)) for s, e in row if e > s] for row in np.asarray(r).reshape(-1, r.shape[-2], 2)]
