@@ -453,12 +453,14 @@ static bool decode_step_plan(int64_t R, int nchunk, int *nw_out, int *ns_out) {
         while (want > ns && R * want > slots) --want;
         ns = want;
     } else {
+        // measured rule (profiles/r03/decode_sweep_split_grid.txt).  A team costs two hand-offs (~2.5 us): a row that fits one workgroup
+        // (<= 2 chunks per wave) is only split when every workgroup then gets 8 chunks (64 KiB: contexts from 32k on, few rows) -- at 16k
+        // the unsplit form wins at every batch size, at 32k with 128 rows too.  A row that must be split anyway gets one chunk per wave
+        // if the chip holds that many workgroups.
         const int ns1 = (nchunk + nw - 1) / nw;  // one chunk per wave
-        if (ns1 > ns && R * ns1 <= slots) ns = ns1;
-        // few rows: spread the K_cmp sweep over more CUs (one CU pulls ~30 GB/s from memory whatever its waves do: MI355X guide, gather table)
-        // -- while every workgroup keeps at least 8 chunks (64 KiB): the two hand-offs of the team form cost ~2.5 us, a 4k context (4 chunks)
-        // is faster on one workgroup
-        while (ns < 16 && R * ns * 2 <= slots / 2 && (nchunk + ns * 2 - 1) / (ns * 2) >= 8) ns *= 2;
+        if (ns >= 2 && ns1 > ns && R * ns1 <= slots) ns = ns1;
+        const int t8 = nchunk / 8;  // workgroups of 8 chunks
+        if (nchunk >= 32 && t8 > ns && R * t8 <= slots) ns = t8;
     }
     *nw_out = nw;
     *ns_out = ns;
