@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import warnings
 from typing import Optional
 
 import torch
@@ -266,6 +267,11 @@ class NSAAttention(nn.Module):
         # on _sdpa_over_ranges (head i sees the first i+1 gathered keys, :1779-1855).  Here that flag routes the selected branch
         # to the two parity-mode executors that reproduce those outputs; everything else stays on the native kernels.
         self._force_parity = os.getenv("NSA_FORCE_PARITY", "0").lower() in ("1", "true", "yes")
+        # A failed native executor is counted and the reference falls back to its next executor and returns normally
+        # (cuda_sel_kernel/__init__.py:60-68, nsa_attention.py:764-782; pinned by nsa/tests/test_cuda_loader_fallback.py:6-38).  Here the
+        # "next executor" of the one-call native layer is the same layer composed from the separate native entry points (still the HIP
+        # kernels; there is no CPU or torch-SDPA executor to fall to).  NSA_HIP_STRICT=1 (read at construction) raises instead.
+        self._strict = os.getenv("NSA_HIP_STRICT", "0").lower() in ("1", "true", "yes")
         self._fallback_counters = {k: 0 for k in ("selection_triton_fails", "selection_cuda_fails", "selection_hip_fails",
                                                   "selection_pack_fails", "selection_mask_fails", "compressed_fa2_fails",
                                                   "sliding_fa2_fails", "total_fallbacks")}
@@ -384,24 +390,30 @@ class NSAAttention(nn.Module):
         else:
             assert x.shape[1] == 1, f"Decode mode requires S=1 (single token), got S={x.shape[1]}."
         self._check_kv(x, kv)
+        one_call = self._native_ok(x)
         try:
             return self._prefill(x, kv) if prefill else self._decode(x, kv)
         except RuntimeError as e:
-            # the reference's router counts a failed native executor and falls back to a safer torch executor
-            # (nsa_attention.py:764-782).  There is no other executor behind this one by design (a silent CPU / eager fallback would void
-            # every parity claim), so the failure is counted where the reference counts it and then raised.
+            # the reference's router counts a failed native executor (nsa_attention.py:764-782) ...
             self._fallback_counters["selection_hip_fails"] += 1
             self._fallback_counters["total_fallbacks"] += 1
             self._last_error = str(e)
-            raise
+            if self._strict or not one_call:
+                raise  # ... the per-stage composition is the last executor there is: no CPU / eager-SDPA route exists by design
+            # ... and falls back to its next executor and returns normally: the layer composed from the separate native calls
+            warnings.warn(f"nsa_vibe_amd: the one-call native layer failed ({e}); falling back to the per-stage native route", RuntimeWarning)
+            try:
+                return self._prefill(x, kv, one_call=False) if prefill else self._decode(x, kv, one_call=False)
+            except Exception:
+                raise e
 
-    def _prefill(self, x: torch.Tensor, kv: NSA_KV):
+    def _prefill(self, x: torch.Tensor, kv: NSA_KV, one_call: bool = True):
         B, S, _ = x.shape
         assert kv.t == 0, "prefill expects an empty cache"
-        native = self._native_ok(x)
+        native = one_call and self._native_ok(x)
         if native:
             return self._prefill_native(x, kv)
-        elif self._train_native_ok(x):
+        elif one_call and self._train_native_ok(x):
             return self._prefill_train_native(x, kv)
         else:
             pos = torch.arange(S, device=x.device)
@@ -522,8 +534,8 @@ class NSAAttention(nn.Module):
         self._last_ranges, self._last_gates = ranges, gates
         return y, kv
 
-    def _decode(self, x: torch.Tensor, kv: NSA_KV):
-        if self._native_ok(x):
+    def _decode(self, x: torch.Tensor, kv: NSA_KV, one_call: bool = True):
+        if one_call and self._native_ok(x):
             return self._decode_native(x, kv)
         t = kv.t  # position of the new token
         pos = torch.tensor([t], device=x.device)

@@ -282,8 +282,9 @@ def test_eq9_slow_path_matches_the_oracle_mapping(nv, orc):
 
 def test_routing_contract_counts_a_failed_native_call_and_raises(monkeypatch):
     """counterpart of nsa/tests/test_cuda_loader_fallback.py:6-38 for the routing contract of nsa_attention.py:764-782: a native call
-    that fails bumps selection_hip_fails / total_fallbacks; there is no other executor to fall back to, so the error is raised
-    (CPU tensors make every native entry refuse)"""
+    that fails bumps selection_hip_fails / total_fallbacks; on the CPU no native executor is left to fall back to (CPU tensors make every
+    native entry refuse: the per-stage composition is already the last one), so the error is raised.  The fall-back of the one-call layer
+    to the per-stage native route is pinned on the GPU (tests/test_hip_module.py::test_native_call_failure_is_counted_and_falls_back)"""
     import torch
 
     from nsa_vibe_amd.nsa_attention import NSAAttention

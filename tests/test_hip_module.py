@@ -650,9 +650,11 @@ def test_force_parity_routing_matches_reference_module(selector, monkeypatch):
     assert m.get_fallback_counters()["total_fallbacks"] == 0
 
 
-def test_native_call_failure_is_counted_and_raised(monkeypatch):
-    """GPU counterpart of test_cuda_loader_fallback.py: the one-call native prefill fails (status != 0) -> RuntimeError carrying the
-    library's message, selection_hip_fails / total_fallbacks bumped, no other route taken"""
+def test_native_call_failure_is_counted_and_falls_back(monkeypatch):
+    """GPU counterpart of nsa/tests/test_cuda_loader_fallback.py:6-38 (contract of cuda_sel_kernel/__init__.py:60-68 and
+    nsa_attention.py:764-782): the one-call native prefill fails (status != 0) -> selection_hip_fails / total_fallbacks bumped, a
+    RuntimeWarning, and the layer RETURNS NORMALLY through its next executor (the same layer composed from the separate native entry
+    points), with the output of the one-call route up to bf16 rounding; NSA_HIP_STRICT=1 (read at construction) raises instead"""
     from nsa_vibe_amd import _lib
     from nsa_vibe_amd.nsa_attention import NSAAttention
 
@@ -660,22 +662,33 @@ def test_native_call_failure_is_counted_and_raised(monkeypatch):
     m = NSAAttention(256, 8, 2, 32, 32, l=32, d=16, l_sel=64, n_sel=8, w=128).cuda().bfloat16().eval()
     x = torch.randn(1, 200, 256, device="cuda", dtype=torch.bfloat16)
     real = _lib.lib()
+    with torch.no_grad():
+        want, _ = m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
 
     class Bad:
         def __getattr__(self, name):
-            if name == "nsa_layer_prefill":
+            if name in ("nsa_layer_prefill", "nsa_layer_decode_step"):
                 return lambda *a: -2
             return getattr(real, name)
 
     monkeypatch.setattr(_lib, "_lib", Bad())
-    with torch.no_grad(), pytest.raises(RuntimeError, match="nsa_layer_prefill failed"):
-        m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="falling back"):
+        out, kv = m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
     c = m.get_fallback_counters()
     assert c["selection_hip_fails"] == 1 and c["total_fallbacks"] == 1
+    assert torch.isfinite(out).all() and (out.float() - want.float()).abs().max().item() <= 6e-2 and kv.t == 200
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="falling back"):  # a decode step through the same contract
+        y, kv = m(torch.randn(1, 1, 256, device="cuda", dtype=torch.bfloat16), kv, prefill=False)
+    assert torch.isfinite(y).all() and kv.t == 201 and m.get_fallback_counters()["total_fallbacks"] == 2
+    monkeypatch.setenv("NSA_HIP_STRICT", "1")
+    ms = NSAAttention(256, 8, 2, 32, 32, l=32, d=16, l_sel=64, n_sel=8, w=128).cuda().bfloat16().eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="nsa_layer_prefill failed"):
+        ms(x, ms.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
+    assert ms.get_fallback_counters()["selection_hip_fails"] == 1
     monkeypatch.setattr(_lib, "_lib", real)
     with torch.no_grad():
-        out, _ = m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
-    assert torch.isfinite(out).all() and m.get_fallback_counters()["total_fallbacks"] == 1
+        out2, _ = m(x, m.new_kv(1, 256, "cuda", torch.bfloat16), prefill=True)
+    assert torch.equal(out2, want) and m.get_fallback_counters()["total_fallbacks"] == 2
 
 
 def test_native_paths_refuse_a_mismatched_cache():
