@@ -50,8 +50,9 @@ struct DecStepParams {
     float c2;
 };
 
-constexpr int DSTEP_PART = 16 * 64 * 2;  // floats: [head][chunk][2]
-constexpr int DSTEP_HALO = 64 * 16;      // floats: [chunk][head] scaled logit of the chunk's last row
+constexpr int DSTEP_CH = 128;                  // chunks of 64 compressed rows per row of the step: contexts up to 128k tokens (S_cmp <= 8192)
+constexpr int DSTEP_PART = 16 * DSTEP_CH * 2;  // floats: [head][chunk][2]
+constexpr int DSTEP_HALO = DSTEP_CH * 16;      // floats: [chunk][head] scaled logit of the chunk's last row
 constexpr int DSTEP_TAIL = 1024 + 4 * (128 + 68 + 4);  // bytes behind the V tiles: mlw [16][16] f32 | scr | list | misc
 static size_t dstep_lds(int nw) { return (size_t)nw * DEC_ATT_TILE + DSTEP_TAIL + (nw == 16 ? 3 * DEC_ATT_TILE : 0); }
 
@@ -160,15 +161,15 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
             if constexpr (SPLIT) {
                 if (rho < h) {  // write-through (sc1) stores: no release fence needed (cdna guide, Guideline 16 R1)
                     if (q == 0)
-                        __hip_atomic_store((unsigned long long *)(P.part_g + (((int64_t)row * h + rho) * 64 + c) * 2),
+                        __hip_atomic_store((unsigned long long *)(P.part_g + (((int64_t)row * h + rho) * DSTEP_CH + c) * 2),
                                            ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (q == 3)
-                        __hip_atomic_store((unsigned *)(P.halo_g + ((int64_t)row * 64 + c) * 16 + rho), __float_as_uint(acc[k][3][3]), __ATOMIC_RELAXED,
+                        __hip_atomic_store((unsigned *)(P.halo_g + ((int64_t)row * DSTEP_CH + c) * 16 + rho), __float_as_uint(acc[k][3][3]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
                 if (rho < h) {
-                    if (q == 0) *(f32x2 *)(part + (rho * 64 + c) * 2) = (f32x2){m, l};
+                    if (q == 0) *(f32x2 *)(part + (rho * DSTEP_CH + c) * 2) = (f32x2){m, l};
                     if (q == 3) halo[c * 16 + rho] = acc[k][3][3];  // row 64 c + 63: the half tap of the next chunk's first block
                 }
             }
@@ -202,16 +203,16 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the compiler from moving the loads below above this point)
         if (misc[2]) {
             // the row's records and edge logits -> LDS, one sc1 load per thread
-            for (int i = threadIdx.x; i < h * 64; i += NW * 64) {
-                const int hh = i >> 6, idx = i & 63;
+            for (int i = threadIdx.x; i < h * DSTEP_CH; i += NW * 64) {
+                const int hh = i / DSTEP_CH, idx = i % DSTEP_CH;
                 if (idx < P.nchunk) {
-                    const unsigned long long r = __hip_atomic_load((const unsigned long long *)(P.part_g + (((int64_t)row * h + hh) * 64 + idx) * 2), __ATOMIC_RELAXED,
+                    const unsigned long long r = __hip_atomic_load((const unsigned long long *)(P.part_g + (((int64_t)row * h + hh) * DSTEP_CH + idx) * 2), __ATOMIC_RELAXED,
                                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    *(f32x2 *)(part + (hh * 64 + idx) * 2) = (f32x2){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
+                    *(f32x2 *)(part + (hh * DSTEP_CH + idx) * 2) = (f32x2){__uint_as_float((unsigned)r), __uint_as_float((unsigned)(r >> 32))};
                 }
             }
             for (int i = threadIdx.x; i < P.nchunk * 16; i += NW * 64)
-                if ((i & 15) < h) halo[i] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.halo_g + (int64_t)row * 64 * 16 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((i & 15) < h) halo[i] = __uint_as_float(__hip_atomic_load((const unsigned *)(P.halo_g + (int64_t)row * DSTEP_CH * 16 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         } else {
             // The team did not assemble within the poll budget (its other workgroups are not resident yet: a second stream or process holds
             // the CUs).  Nobody waits for anybody here: this workgroup forms the records and edge logits of ALL chunks of the row itself --
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
                         if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(z[u][j] - m);
                 l = xor32_add(xor16_add(l));
                 if (rho < h) {
-                    if (q == 0) *(f32x2 *)(part + (rho * 64 + c) * 2) = (f32x2){m, l};
+                    if (q == 0) *(f32x2 *)(part + (rho * DSTEP_CH + c) * 2) = (f32x2){m, l};
                     if (q == 3) halo[c * 16 + rho] = z[3][3];
                 }
             }
@@ -262,30 +263,33 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     // ---- phase 2a: per-head log-sum-exp of the row's logits from the chunk records, by every wave for itself.  One 16-lane row of the
     // wave per head, lane i holds records i, i+16, i+32, i+48: ((a_i + a_{i+32}) + (a_{i+16} + a_{i+48})) then xor 8, 4, 2, 1 is the
     // summation tree of wave_sum over 64 lanes (decode_pgrp_kernel / the round-2 fused kernel): same bits.
-    const int nr4 = (P.nchunk + 15) >> 4;  // records per lane that exist at all (a context of 16k has 16 chunks: one)
+    const int nr = (P.nchunk + 15) >> 4;  // records per lane that exist at all (a context of 16k has 16 chunks: one; 128k: eight)
     for (int h0 = 0; h0 < h; h0 += 4) {
         const int hh = h0 + q;
-        float mv[4], lv[4];
+        float mv[8], lv[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int idx = rho + 16 * i;
             mv[i] = -INFINITY;
             lv[i] = 0.f;
-            if (i < nr4 && hh < h && idx < P.nchunk) {
-                const f32x2 r = *(const f32x2 *)(part + (hh * 64 + idx) * 2);
+            if (i < nr && hh < h && idx < P.nchunk) {
+                const f32x2 r = *(const f32x2 *)(part + (hh * DSTEP_CH + idx) * 2);
                 mv[i] = r[0];
                 lv[i] = r[1];
             }
         }
-        float m = fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3]));
+        float m = fmaxf(fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3])), fmaxf(fmaxf(mv[4], mv[5]), fmaxf(mv[6], mv[7])));
         m = fmaxf(m, row_ror<8>(m));  // butterfly over the 16 lanes of the row by DPP rotations (nsa_common.hpp: no LDS crossbar on the chain)
         m = fmaxf(m, row_ror<4>(m));
         m = fmaxf(m, row_ror<2>(m));
         m = fmaxf(m, row_ror<1>(m));
         float av[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)  // (a record that does not exist adds +0: exact, so skipping its exponential changes nothing)
-            av[i] = (i < nr4 && rho + 16 * i < P.nchunk) ? lv[i] * __builtin_amdgcn_exp2f(mv[i] - m) : 0.f;
+        for (int i = 0; i < 4; ++i) {  // (a record that does not exist adds +0: exact, so skipping its exponential changes nothing)
+            av[i] = (i < nr && rho + 16 * i < P.nchunk) ? lv[i] * __builtin_amdgcn_exp2f(mv[i] - m) : 0.f;
+            // beyond 64 chunks the three-kernel route lets lane L add records L and L + 64 before the butterfly: the same sum here
+            if (i + 4 < nr && rho + 16 * (i + 4) < P.nchunk) av[i] += lv[i + 4] * __builtin_amdgcn_exp2f(mv[i + 4] - m);
+        }
         float s = (av[0] + av[2]) + (av[1] + av[3]);
         s += row_ror<8>(s);
         s += row_ror<4>(s);
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
             case 4: select_topn_row_regs<4>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
             case 8: select_topn_row_regs<8>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
             case 16: select_topn_row_regs<16>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
-            default: select_topn_row_regs<32>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            default: select_topn_row_regs<32, true>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
         }
         if (lane == 0) misc[0] = nb;
     }
@@ -424,7 +428,7 @@ static int *decode_tickets(hipStream_t st, int64_t rows) {
 
 size_t decode_step_workspace(int64_t R, int h, int S_cmp) {  // split form: chunk records, edge logits, group scores of every row
     (void)S_cmp;
-    return sizeof(float) * (size_t)R * ((size_t)h * 64 * 2 + 64 * 16 + 2048);
+    return sizeof(float) * (size_t)R * ((size_t)h * DSTEP_CH * 2 + DSTEP_CH * 16 + 2048);
 }
 
 static int device_cu_count() {
@@ -474,7 +478,7 @@ bool decode_step_supported(int64_t R, int dtype, int h, int Dk, int Dv, int S_cm
     int nw, ns;
     if (R < 1 || S_cmp < 1 || !decode_step_plan(R, (S_cmp + 63) / 64, &nw, &ns)) return false;
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16 && d > 0 && l == 2 * d && l_sel == 4 * d &&
-           l_sel == 64 && S_cmp >= 1 && S_cmp <= 64 * 64 && S_sel >= 1 && S_sel <= 2048 && n_top >= 3 && n_top <= 64 && t_token >= 0 &&
+           l_sel == 64 && S_cmp >= 1 && S_cmp <= 64 * DSTEP_CH && S_sel >= 1 && S_sel <= 2048 && n_top >= 3 && n_top <= 64 && t_token >= 0 &&
            S_kv >= t_token + 1 && (int64_t)S_kv * 128 < ((int64_t)1 << 31) && kcs % 8 == 0 && kcb % 8 == 0 && kcg % 8 == 0 &&
            ((uintptr_t)Kc % 16 == 0) && sel_attn_decode_wg_supported(dtype, h, Dk, Dv, n_top, ksb, ksg, kss, vsb, vsg, vss, Q, K, V);
 }
@@ -492,8 +496,8 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     if (ns > 1) {
         NSA_CHECK_ARG(ws && ws_bytes >= decode_step_workspace(R, h, S_cmp) && ((uintptr_t)ws % 16 == 0), "decode step: workspace too small");
         P.part_g = (float *)ws;
-        P.halo_g = P.part_g + (size_t)R * h * 64 * 2;
-        P.pg_g = P.halo_g + (size_t)R * 64 * 16;
+        P.halo_g = P.part_g + (size_t)R * h * DSTEP_CH * 2;
+        P.pg_g = P.halo_g + (size_t)R * DSTEP_CH * 16;
         P.cnt = decode_tickets(st, 2 * R);
         NSA_CHECK_ARG(P.cnt != nullptr, "decode step: could not allocate the arrival tickets");
     }
@@ -514,7 +518,8 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     else k = nw == 16 ? (split ? NSA_DSK(16, true, 0) : NSA_DSK(16, false, 0)) : (split ? NSA_DSK(8, true, 0) : NSA_DSK(8, false, 0));
 #undef NSA_DSK
     const size_t lds = dstep_lds(nw);
-    NSA_CHECK_ARG(sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)S_sel) <= 3 * (size_t)DEC_ATT_TILE, "decode step: S_sel too large");
+    // the score data sits in V tiles 1 .. (the prefetching waves of the 16-wave form own tiles 0, 14, 15)
+    NSA_CHECK_ARG(sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)S_sel) <= (size_t)(nw == 16 ? 13 : nw) * DEC_ATT_TILE, "decode step: S_sel too large");
     {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
         static std::mutex mu;
         static void *raised[16] = {};

@@ -243,7 +243,7 @@ def test_fuzz_training_gradients_native_vs_eager(seed, monkeypatch):
 
 @pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_decode_step(nv, orc, seed, tune):
-    """the one-launch decode step over random shapes -- contexts from a few tokens to 20k (t not a multiple of anything, caches longer
+    """the one-launch decode step over random shapes -- contexts from a few tokens to 131k (t not a multiple of anything, caches longer
     than the context, contexts before the first compressed token / the first complete block / the third block, where the forced blocks
     collapse and nothing is fetched ahead), 1..16 heads per group, 3..24 ranges per row, up to 48 rows, 16 / 8 waves, split or not --
     against the three separate launches (ranges and O bit-identical) and the oracle (selector on the device scores; attention)."""
@@ -252,7 +252,7 @@ def test_fuzz_decode_step(nv, orc, seed, tune):
     B, G = int(rng.integers(1, 13)), int(rng.choice([1, 2, 4]))
     h = int(rng.choice([1, 2, 3, 4, 6, 6, 6, 8, 12, 16]))
     n = int(rng.choice([3, 4, 8, 16, 16, 16, 24]))
-    t = int(rng.choice([int(rng.integers(0, 64)), int(rng.integers(64, 200)), int(rng.integers(200, 3000)), int(rng.integers(3000, 20000))]))
+    t = int(rng.choice([int(rng.integers(0, 64)), int(rng.integers(64, 200)), int(rng.integers(200, 3000)), int(rng.integers(3000, 20000)), int(rng.integers(60000, 131000))]))
     S_ctx = t + 1 + int(rng.integers(0, 70))  # the cache may hold more tokens than the step may see
     D = 64
     meta = nv.build_block_meta(t + 1, 32, 16, 64, n, 512)

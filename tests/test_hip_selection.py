@@ -641,7 +641,7 @@ def test_scorer_64bit_output_offsets(nv, orc):
     assert norm(rs) == norm(want)
 
 
-@pytest.mark.parametrize("S_ctx,B", [(64, 2), (700, 3), (1041, 2), (4096, 5), (16384, 3), (40000, 2), (65536, 2)])
+@pytest.mark.parametrize("S_ctx,B", [(64, 2), (700, 3), (1041, 2), (4096, 5), (16384, 3), (40000, 2), (65536, 2), (65600, 2), (100001, 1), (131072, 2)])
 def test_decode_step_kernel_forms_agree(nv, orc, tune, S_ctx, B):
     """the one-launch decode step (sel_decode_fused.hip) in every form -- 16 / 8 waves per row, the logits phase of a row on one
     workgroup or split over 2 / 4 / 16 (the last arriver finishes the row) -- against the three separate launches (DECODE_UNFUSED = 1)
