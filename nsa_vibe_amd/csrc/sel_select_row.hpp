@@ -31,29 +31,29 @@ __device__ __forceinline__ void extract_runs_lanes(const unsigned long long (&wd
     const int lane = lane_id();
     my_s = 0;
     my_e = 0;
-        int n_s = 0, n_e = 0;  // runs started / ended in the words so far (wave uniform)
+    int n_s = 0, n_e = 0;  // runs started / ended in the words so far (wave uniform)
 #pragma unroll
-        for (int c = 0; c < CAND; ++c) {
-            const unsigned long long w = wd[c];
-            if (w == 0ull) continue;
-            const unsigned long long below = c > 0 ? (wd[c > 0 ? c - 1 : 0] >> 63) : 0ull;             // block 64c - 1 selected
-            const unsigned long long above = c + 1 < CAND ? (wd[c + 1 < CAND ? c + 1 : c] << 63) : 0ull;  // block 64c + 64 selected
-            const unsigned long long sm = w & ~((w << 1) | below);  // blocks that start a run
-            const unsigned long long em = w & ~((w >> 1) | above);  // blocks that end one
-            const int blk = 64 * c + lane;
-            // (the scalar masks predicate the lanes directly; the run counts so far enter the bit counts as their start value)
-            if (__builtin_amdgcn_inverse_ballot_w64(sm))
-                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, (unsigned)n_s))] = blk * l_sel;
-            if (__builtin_amdgcn_inverse_ballot_w64(em))
-                scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, (unsigned)n_e)) + 1] =
-                    min((blk + 1) * l_sel, t + 1);
-            n_s += __popcll(sm);
-            n_e += __popcll(em);
-        }
-        if (lane < n_s) {  // the i-th start pairs with the i-th end: runs are disjoint and ascending
-            my_s = scr[2 * lane];
-            my_e = scr[2 * lane + 1];
-        }
+    for (int c = 0; c < CAND; ++c) {
+        const unsigned long long w = wd[c];
+        if (w == 0ull) continue;
+        const unsigned long long below = c > 0 ? (wd[c > 0 ? c - 1 : 0] >> 63) : 0ull;             // block 64c - 1 selected
+        const unsigned long long above = c + 1 < CAND ? (wd[c + 1 < CAND ? c + 1 : c] << 63) : 0ull;  // block 64c + 64 selected
+        const unsigned long long sm = w & ~((w << 1) | below);  // blocks that start a run
+        const unsigned long long em = w & ~((w >> 1) | above);  // blocks that end one
+        const int blk = 64 * c + lane;
+        // (the scalar masks predicate the lanes directly; the run counts so far enter the bit counts as their start value)
+        if (__builtin_amdgcn_inverse_ballot_w64(sm))
+            scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, (unsigned)n_s))] = blk * l_sel;
+        if (__builtin_amdgcn_inverse_ballot_w64(em))
+            scr[2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, (unsigned)n_e)) + 1] =
+                min((blk + 1) * l_sel, t + 1);
+        n_s += __popcll(sm);
+        n_e += __popcll(em);
+    }
+    if (lane < n_s) {  // the i-th start pairs with the i-th end: runs are disjoint and ascending
+        my_s = scr[2 * lane];
+        my_e = scr[2 * lane + 1];
+    }
 }
 
 // one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS).  Lane i < min(W, 64) returns
