@@ -147,6 +147,17 @@ __device__ __forceinline__ float row_ror(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 | N, 0xf, 0xf, false));
 }
 
+// maximum of an unsigned value over the wave (uniform result): four DPP rotations inside the 16-lane rows, then the row and half swaps
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define NSA_ROR_MAX(N) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 | N, 0xf, 0xf, false));
+    NSA_ROR_MAX(8) NSA_ROR_MAX(4) NSA_ROR_MAX(2) NSA_ROR_MAX(1)
+#undef NSA_ROR_MAX
+    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = max(a[0], a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)max(b[0], b[1]));
+}
+
 // make LDS traffic of this wave visible to its own later LDS reads (wave-private regions only:
 // DS operations of one wave execute in order, the fence only pins the compiler).
 __device__ __forceinline__ void wave_lds_fence() {

@@ -214,7 +214,36 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
             DEC_TS(23);
             unsigned T = 0;
             bool exact = false;
-            for (int bit = 31; bit >= 0; --bit) {
+            int bit0 = 31;
+            {
+                // the first nine rounds (sign + exponent of the k-th key) in at most two probes: the k-th largest key cannot exceed the
+                // largest one, M; if at least k keys share M's top nine bits that IS the prefix of the k-th key, otherwise it is tried one
+                // exponent lower (scores of one row rarely spread over more than two octaves), otherwise the search starts from the top bit.
+                // Any prefix P with count(>= P) >= k > count(>= P + 2^23) is the one the bit-by-bit search arrives at: same T, same picks.
+                unsigned lm = w[0];
+                if constexpr (!SORTED) {
+#pragma unroll
+                    for (int c = 1; c < CAND; ++c) lm = max(lm, w[c]);
+                }
+                const unsigned p1 = wave_max_u32(lm) & 0xFF800000u;
+                if (p1 != 0u) {
+                    const int c1 = count_ge(p1, k_eff);
+                    if (c1 >= k_eff) {
+                        T = p1;
+                        bit0 = 22;
+                        exact = c1 == k_eff;
+                    } else if (p1 > 0x00800000u) {
+                        const unsigned p2 = p1 - 0x00800000u;
+                        const int c2 = count_ge(p2, k_eff);
+                        if (c2 >= k_eff) {
+                            T = p2;
+                            bit0 = 22;
+                            exact = c2 == k_eff;
+                        }
+                    }
+                }
+            }
+            for (int bit = bit0; bit >= 0 && !exact; --bit) {
                 const unsigned cand = T | (1u << bit);
                 const int c = count_ge(cand, k_eff);
                 if (c >= k_eff) T = cand;
