@@ -322,13 +322,13 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
 }
 
 template <typename T, int D, int NT, bool SPLIT, int STAGE>
-__global__ __launch_bounds__(256) void band_attn_fwd_kernel(BandAttnParams P) {
+__global__ __launch_bounds__(256, 2) void band_attn_fwd_kernel(BandAttnParams P) {
     band_attn_body<T, D, NT, SPLIT, STAGE>(P, blockIdx.x);
 }
 
 // decode: the sliding and the compressed branch of one step in ONE launch (two argument blocks, split-KV form)
 template <typename T, int D>
-__global__ __launch_bounds__(256) void band_attn_fwd_dual_kernel(BandAttnParams P0, BandAttnParams P1, unsigned grid0) {
+__global__ __launch_bounds__(256, 2) void band_attn_fwd_dual_kernel(BandAttnParams P0, BandAttnParams P1, unsigned grid0) {
     if (blockIdx.x < grid0) band_attn_body<T, D, 1, true, 1>(P0, blockIdx.x);
     else band_attn_body<T, D, 1, true, 1>(P1, blockIdx.x - grid0);
 }
@@ -348,7 +348,7 @@ struct BandBwdExtra {
 };
 
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void band_attn_bwd_dq_kernel(BandAttnParams P, BandBwdExtra E) {
+__global__ __launch_bounds__(256, 2) void band_attn_bwd_dq_kernel(BandAttnParams P, BandBwdExtra E) {
     using M = MfmaT<T>;
     using G_ = Geo<64>;
     using x8 = typename M::x8;

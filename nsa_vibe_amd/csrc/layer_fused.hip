@@ -347,7 +347,7 @@ __device__ __forceinline__ void rope_store_pair(const RopeAppendParams &P, int b
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W, int K,
+__global__ __launch_bounds__(256, 2) void qkv_rope_append_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W, int K,
                                                               const T *__restrict__ norm_w, float norm_eps) {
     const int lane = lane_id();
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void qkv_rope_append_kernel(RopeAppendParams P
 // fragment shape), the rows of X the B operand (L1/L2 resident), all loads of a wave issued before its first MFMA; the four
 // K-partials meet in LDS.  Thread t of the epilogue owns row m = t % 64 and columns 4 (t / 64) .. +3 (two rotation pairs).
 template <typename T, bool ROPE>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
+__global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
                                                           T *__restrict__ out, int M, int N, int K, int epi, const T *__restrict__ res) {
     using MT_ = MfmaT<T>;
     using x8 = typename MT_::x8;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void bwd_delta_kernel(const T *__restrict__ O,
 
 // ------------------------------------------------------------------------------------------ 2. dQ (query-major)
 template <typename T>
-__global__ __launch_bounds__(256) void bwd_dq_kernel(SelAttnBwdParams P, const float *__restrict__ delta, int map_mode) {
+__global__ __launch_bounds__(256, 2) void bwd_dq_kernel(SelAttnBwdParams P, const float *__restrict__ delta, int map_mode) {
     using M = BwdT<T>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
@@ -286,7 +286,7 @@ __device__ __forceinline__ void bwd_lds_or(unsigned *p, unsigned v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bwd_dq_rows_kernel(SelAttnBwdParams P, const float *__restrict__ delta, int map_mode, int tpw, int NW,
+__global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P, const float *__restrict__ delta, int map_mode, int tpw, int NW,
                                                           int wave_lds) {
     using M = BwdT<T>;
     using x8 = typename M::x8;
@@ -560,7 +560,7 @@ __device__ unsigned long long g_dbg[4 * 65536];
 #endif  // column tiles (of 16 (query,head) slots) staged per round
 
 template <typename T>
-__global__ __launch_bounds__(256) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta, float *__restrict__ part,
+__global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta, float *__restrict__ part,
                                                         const unsigned long long *__restrict__ hitmap, int *__restrict__ flags,
                                                         int rows_per_split, int nkb, int nbg, int nsplit) {
     using M = BwdT<T>;

@@ -36,7 +36,7 @@ namespace nsa {
 // STAGE 1: tiles are written into LDS by LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR / ds_write on the path); the
 //          XOR swizzle is applied on the per-lane SOURCE offset because the DMA destination is lane-linear.
 template <typename T, int D, bool SPLIT, int STAGE>
-__global__ __launch_bounds__(256) void sel_attn_fwd_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
+__global__ __launch_bounds__(256, 2) void sel_attn_fwd_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     using M = MfmaT<T>;
     using G_ = Geo<D>;
     using x8 = typename M::x8;

@@ -42,7 +42,7 @@ __device__ __forceinline__ void lds_or(unsigned *p, unsigned v) {  // ds_or_b32:
 
 // RS: row sums of P on the matrix pipe (l += ones . P^T, one MFMA per tile instead of 8 v_add; see sel_attn_blocks_mfma.hip)
 template <typename T, int D, int NT, bool RS>
-__global__ __launch_bounds__(256) void sel_attn_rows_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
+__global__ __launch_bounds__(256, 2) void sel_attn_rows_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     using M = MfmaT<T>;
     using G_ = Geo<D>;
     using x8 = typename M::x8;

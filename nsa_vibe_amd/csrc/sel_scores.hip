@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void decode_logits_kernel(DecodeParams P) {
 // kernel 1, MFMA form (bf16/f16, Dk % 32 == 0, h <= 16): the 64 compressed rows of the chunk are the MFMA rows,
 // the h heads the 16 columns; K_cmp fragments are loaded straight into the A-operand layout (one pass, no reuse).
 template <typename T, int KSTEPS>
-__global__ __launch_bounds__(64) void decode_logits_mfma_kernel(DecodeParams P) {
+__global__ __launch_bounds__(64, 2) void decode_logits_mfma_kernel(DecodeParams P) {
     typedef typename std::conditional<std::is_same<T, __bf16>::value, bf16x8, f16x8>::type x8;
     const int lane = threadIdx.x, rho = lane & 15, q = lane >> 4;
     const int64_t row = blockIdx.y;

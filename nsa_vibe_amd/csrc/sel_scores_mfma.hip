@@ -59,7 +59,7 @@ struct MfmaS<_Float16> {
 // this kernel is the SUM of its MFMA and VALU cycles and every unused column costs both.  Queries 2 and 5 of the eight straddle two tiles:
 // their head sum takes the tail of one tile's shifted sums and the head of the next one's (one more DPP add each).
 template <typename T, int D, int NT, int HC>
-__global__ __launch_bounds__(256) void scores_mfma_kernel(ScoresMfmaParams P) {
+__global__ __launch_bounds__(256, 2) void scores_mfma_kernel(ScoresMfmaParams P) {
     constexpr bool FLAT = (HC == 6 && NT == 3);
     using M = MfmaS<T>;
     using x8 = typename M::x8;

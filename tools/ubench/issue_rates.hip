@@ -1,22 +1,25 @@
 // Issue-rate microbenchmark for gfx950 (run on the GPU box):  hipcc --offload-arch=gfx950 -O2 -o issue_rates issue_rates.hip && ./issue_rates
 // Each kernel runs ITERS x UNROLL copies of one instruction pattern per wave; W waves per SIMD (one 256-thread workgroup = one wave per SIMD,
 // W workgroups per CU).  Reported: SIMD cycles per pattern instance = time x clock x (1 / (ITERS x UNROLL x W)), i.e. the reciprocal issue rate the
-// SIMD sustains with W waves to pick from.  Patterns: fma, pk_fma, exp, mfma 16x16x32 bf16, and MFMA + VALU mixes.
+// SIMD sustains with W waves to pick from.  Patterns: fma, pk_fma, exp, mfma 16x16x32 / 32x32x16 bf16, and MFMA + VALU mixes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int ITERS = 2000;
 
 #define REP8(X) X X X X X X X X
+#define REP2(X) X X
 
 template <int PAT>
 __global__ __launch_bounds__(256) void k(float *out) {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b0 = 1.0001f, c0 = 0.5f;
     f32x4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+    f32x16 w0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, w1 = w0;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     f32x2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {1.0001f, 1.0001f}, pc = {0.5f, 0.5f};
     bf16x8 fa, fb;
@@ -79,9 +82,41 @@ __global__ __launch_bounds__(256) void k(float *out) {
             for (int j = 0; j < 4; ++j) a0 += __builtin_amdgcn_exp2f(fmaf(m0[j], b0, c0));
 #pragma unroll
             for (int j = 0; j < 4; ++j) a1 += __builtin_amdgcn_exp2f(fmaf(m1[j], b0, c0));
+        } else if (PAT == 9) {  // 2 independent MFMA 32x32x16 bf16 (the flops of 4 x 16x16x32)
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+        } else if (PAT == 10) {  // 2 MFMA 32x32x16 + 8 fma
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(c0));
+        } else if (PAT == 11) {  // 2 MFMA 32x32x16 + 16 fma
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(c0));
+        } else if (PAT == 12) {  // 2 MFMA 32x32x16 + 8 exp
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (PAT == 13) {  // 2 MFMA 32x32x16 + 32 fma (VALU-heavy mix: does the matrix time hide?)
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile(REP2(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile(REP2(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n")) : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(c0));
+        } else if (PAT == 14) {  // 4 MFMA 16x16x32 + 32 fma
+            m0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, m0, 0, 0, 0);
+            asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0));
+            m1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, m1, 0, 0, 0);
+            asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(c0));
+            m2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, m2, 0, 0, 0);
+            asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0));
+            m3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, m3, 0, 0, 0);
+            asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(c0));
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + m0[0] + m1[1] + m2[2] + m3[3] + p0[0] + p1[1] + p2[0] + p3[1];
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + m0[0] + m1[1] + m2[2] + m3[3] + p0[0] + p1[1] + p2[0] + p3[1] + w0[0] + w1[5];
 }
 
 template <int PAT>
@@ -119,5 +154,11 @@ int main() {
     run<6>("4 x mfma + 8 x exp", 12, out, ghz, n);
     run<7>("8 x fma + 8 x exp", 16, out, ghz, n);
     run<8>("2 x (2 dep. mfma) + 8 x (fma, exp, add)", 28, out, ghz, n);
+    run<9>("2 x mfma 32x32x16 bf16", 2, out, ghz, n);
+    run<10>("2 x mfma32 + 8 x fma", 10, out, ghz, n);
+    run<11>("2 x mfma32 + 16 x fma", 18, out, ghz, n);
+    run<12>("2 x mfma32 + 8 x exp", 10, out, ghz, n);
+    run<13>("2 x mfma32 + 32 x fma", 34, out, ghz, n);
+    run<14>("4 x mfma16 + 32 x fma", 36, out, ghz, n);
     return 0;
 }
