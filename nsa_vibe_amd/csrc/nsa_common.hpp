@@ -45,7 +45,7 @@ enum Tune {
     TUNE_SEL_ROWSUM,        // NSA_HIP_SEL_ROWSUM: block-form forward, row sums of P by MFMA (1) or by v_add (0)
     TUNE_DECODE_STENCIL,    // NSA_HIP_DECODE_STENCIL: fused decode kernel, 1 = closed-form Eq.9 taps for l = 2d, l' = 4d; 0 = always the CSC
     TUNE_SEL_FUSE,          // NSA_HIP_SEL_FUSE: nsa_sel_select_attn_fwd, 1 = the selector runs inside the attention launch, 0 = two launches
-    TUNE_SCORES_FORM,       // NSA_HIP_SCORES_FORM: fused scorer with h = 6, 1 = 8 queries on 3 column tiles (no idle columns), 0 = on 4 tiles
+    TUNE_SCORES_FORM,       // NSA_HIP_SCORES_FORM: fused scorer with h = 6: -1 / 2 = 32x32x16 tiles, 16 queries per wave (D = 64), 1 = 16x16x32 tiles with 8 queries on 3 column tiles, 0 = on 4 tiles
     TUNE_SEL_FLAT,          // NSA_HIP_SEL_FLAT: block-form attention with h = 6, 1 = 8 rows on 3 column tiles (no idle columns), 0 = on 4 tiles, -1 = by context length
     TUNE_SEL_KSPLIT,        // NSA_HIP_SEL_KSPLIT: block-form attention with the keys of a pair split over two XCD groups: -1 by shape, 0 never, 1 always
     TUNE_DECODE_STOP,       // NSA_HIP_DECODE_STOP: measurement aid, the fused decode kernel returns after phase N (1 logits, 2 scores, 3 top-n); 0 = run all
@@ -63,6 +63,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;

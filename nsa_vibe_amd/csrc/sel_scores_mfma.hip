@@ -20,21 +20,9 @@
 // end), sweep 2 = recompute logits, normalise, stencil, head sum, store.  With causal_skip the
 // second sweep stops at the last selection block any query of the workgroup may select
 // ((j+1) l' <= t+1); blocks beyond are never read by the selector (masked to -inf there).
-#include "nsa_common.hpp"
+#include "sel_scores_mfma.hpp"
 
 namespace nsa {
-
-struct ScoresMfmaParams {
-    const void *Q;   // [B,S,G,h,D]
-    const void *Kc;  // [B,G,S_cmp,D] strided
-    float *p_grp;    // [B,S,G,S_sel]
-    int B, S, G, h, S_cmp, S_sel;
-    int64_t csb, csg, css;
-    float scale;
-    int causal_skip;
-    int d_stride;  // the compression stride d (tokens); l' = 4d
-    int big_out;   // S G S_sel >= 2^31 elements per sequence: 64-bit output offsets
-};
 
 template <typename T>
 struct MfmaS;
@@ -398,6 +386,8 @@ int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, i
     if (causal_skip != 2) NSA_HIP_TRY(hipMemsetAsync(p_grp, 0, sizeof(float) * (size_t)B * S * G * S_sel, st));
     ScoresMfmaParams P{Q, Kc, p_grp, B, S, G, h, S_cmp, S_sel, csb, csg, css, scale, causal_skip, d_stride,
                        (int64_t)S * G * S_sel < ((int64_t)1 << 31) ? 0 : 1};
+    const int form = tuning(TUNE_SCORES_FORM);
+    if ((form < 0 || form == 2) && scores_mfma32_supported(P, Dk)) return launch_scores_mfma32(P, dtype, st);
     if (dtype == NSA_DT_BF16) return Dk == 64 ? launch_scores_t<__bf16, 64>(P, st) : launch_scores_t<__bf16, 128>(P, st);
     return Dk == 64 ? launch_scores_t<_Float16, 64>(P, st) : launch_scores_t<_Float16, 128>(P, st);
 }

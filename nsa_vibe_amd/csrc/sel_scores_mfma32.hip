@@ -1,0 +1,375 @@
+// Fused selection scorer on 32x32x16 MFMA tiles (gfx950), h = 6 heads per group and D = 64: Q, K_cmp -> p_grp.
+//
+// Same reference chain and the same two sweeps as sel_scores_mfma.hip (compute_pcmp_all, selection_scorer.py:42-61 ->
+// map_pcmp_to_pslc_batched, :89-116 -> .sum(dim=3), nsa_attention.py:1091; Eq.9 as the 5-tap stencil of l = 2d, l' = 4d).  What changes is
+// the tile shape and, in the second sweep, which operand supplies the MFMA rows.
+//
+// Cost model (tools/ubench/issue_rates.hip, profiles/r03/issue_rates.txt and scorer_notes.txt; cycles of one SIMD at the nominal clock, two or
+// more waves to pick from): v_fma / v_add / v_mul 2.6, v_pk_fma_f32 4.9-5.8 (two plain ops cost the same), DPP add 4.2, v_exp_f32 8.2,
+// MFMA 32x32x16 35.8, MFMA 16x16x32 19.5 (9 % more per flop).  Matrix and vector instructions of a SIMD do NOT run side by side to any
+// useful degree, whatever the tile shape, the number of resident waves (2 or 3) or their relative phase: with 3 of the 4 k-steps removed this
+// kernel loses exactly the time of the removed MFMAs, with v_exp_f32 replaced by a multiply exactly the difference of their costs.  The time
+// of a scorer is the SUM of its instruction costs; this form is the one with the smallest sum found:
+// * 32x32x16 tiles: 9 % less matrix time for the same flops, half the LDS reads per query.
+// * One wave = 16 queries = 96 (query, head) pairs = three 32-wide tiles, no idle column; one workgroup = 4 waves = 64 queries sharing the
+//   K_cmp tile in LDS.
+// * Sweep 1 (row max / row sum): S^T = K_cmp tile [32 x D] . Q^T [D x 32]: compressed keys are the MFMA rows, a lane owns ONE (query, head)
+//   column per tile, so the running reference max and sum are one register each per tile.  Per logit: v_fma, v_exp, v_add.
+// * Sweep 2 (normalise, Eq.10 head sum, Eq.9 stencil, store): the operands swap, S = Q [32 x D] . K_cmp^T [D x 32]: a lane owns one
+//   COMPRESSED KEY (column) and 16 (query, head) rows per tile.  The head sum is then plain adds inside the lane (the 6 rows of a query are
+//   4 + 2 registers of the two lane halves: two v_permlane32_swap per 4 queries carry the 2-row parts across), and the stencil runs along the
+//   lanes on the head-summed value: 6 DPP operations per (query, 8 selection blocks) instead of a stencil per head and 17 DPP adds per 12
+//   logits for the head sum.
+//   The summation order differs from the 16x16 form (heads first, then taps): same fp32 arithmetic, last-bit differences.
+// Per 32 compressed rows x 96 pairs and wave: sweep 1 = 12 MFMA + 48 x (fma, exp, add) ~ 1,100 cycles, sweep 2 = 12 MFMA + 48 x (fma, exp) +
+// ~60 head-sum + 48 stencil operations ~ 1,380; floor of the two-sweep algorithm (MFMA + exp + one fma per logit, nothing else) ~ 950 each.
+// Ablation switches (timing only, results meaningless; tools/ablate_scorer.sh): SC32_KSTEPS=n keeps n of the 4 k-steps, SC32_NOEXP replaces
+// v_exp_f32 by a multiply, SC32_NOSYNC drops staging and barriers, SC32_SWEEP1 stops after the first sweep.
+#include "sel_scores_mfma.hpp"
+#ifdef SC32_NOEXP  // ablation: a full-rate VALU op in place of v_exp_f32
+#define SC32_EXP(x) ((x) * 0.001f)
+#else
+#define SC32_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
+#ifdef SC32_KSTEPS  // ablation build: only the first SC32_KSTEPS of the 4 k-steps (timing only, results meaningless)
+#define SC32_MMA(a, b, c) (s < SC32_KSTEPS ? M::mma(a, b, c) : c)
+#else
+#define SC32_MMA(a, b, c) M::mma(a, b, c)
+#endif
+
+namespace nsa {
+
+template <typename T>
+struct Mfma32;
+template <>
+struct Mfma32<__bf16> {
+    using x8 = bf16x8;
+    __device__ static f32x16 mma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mfma32<_Float16> {
+    using x8 = f16x8;
+    __device__ static f32x16 mma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// Lane layout of one 32x32x16 MFMA (tools/ubench/probe_lanes.hip): A row and B column = lane & 31, both with k = 8 (lane >> 5) + e;
+// acc[i] of a lane = C[8 (i >> 2) + 4 (lane >> 5) + (i & 3)][lane & 31].
+template <typename T>
+__global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams P) {
+    using M = Mfma32<T>;
+    using x8 = typename M::x8;
+    constexpr int D = 64, HC = 6;
+    constexpr int ROWB = D * 2;
+    constexpr int TILE_ROWS = 64;              // K_cmp rows per LDS tile (one barrier per tile; 128 and 256 measured slower: registers)
+    constexpr int NH = TILE_ROWS / 32;         // 32-row halves per tile
+    constexpr int NLD = TILE_ROWS / 32;        // 16-B pieces per thread per tile
+    constexpr int TILE_BYTES = TILE_ROWS * ROWB;
+    constexpr int QPW = 16, QW = 64;  // queries per wave / workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float mlg[4][96];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
+    const int r = lane & 31, half = lane >> 5;
+    const int bg = blockIdx.y;
+    const int b = bg / P.G, g = bg % P.G;
+    // late query tiles first (longest second sweep first), as in the 16x16 form
+    const int t0 = (P.causal_skip ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QW;
+    const int tw = t0 + wave * QPW;
+    const T *Kc = (const T *)P.Kc + (int64_t)b * P.csb + (int64_t)g * P.csg;
+    const float c2 = P.scale * LOG2E;
+
+    // ---- Q fragments: row / column 32 n + r of the wave's 96 (query, head) pairs, k-step s = dims 16 s + 8 half ..
+    x8 qf[3][4];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int R = 32 * n + r;
+        const int t = tw + R / HC, hh = R % HC;
+        const bool ok = t < P.S;
+        const T *qr = (const T *)P.Q + ((((int64_t)b * P.S + (ok ? t : 0)) * P.G + g) * HC + hh) * (int64_t)D;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (ok) raw = *(const u32x4 *)(qr + 16 * s + 8 * half);
+            qf[n][s] = __builtin_bit_cast(x8, raw);
+        }
+    }
+
+    const int ntiles = (P.S_cmp + TILE_ROWS - 1) / TILE_ROWS;
+    // staging of one 64-row K_cmp tile: thread -> 2 (row, 16-B piece) pairs.  LDS piece swizzle (row >> 1) & 7: the 16 rows x one piece a
+    // quarter-wave reads, and the 2 rows x 8 pieces it writes, both cover the 64 banks exactly once.
+    u32x4 stg[NLD];
+    unsigned toff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int p = tid + 256 * i;
+        toff[i] = (unsigned)((p >> 3) * (int)P.css + (p & 7) * 8) * (unsigned)sizeof(T);
+    }
+    const bool small_stride = P.css * (int64_t)TILE_ROWS * (int64_t)sizeof(T) < ((int64_t)1 << 31);
+    auto load_tile = [&](int tile) {
+        if (small_stride && (tile + 1) * TILE_ROWS <= P.S_cmp) {
+            const unsigned char *base = (const unsigned char *)(Kc + (int64_t)tile * TILE_ROWS * P.css);  // wave uniform
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) stg[i] = *(const u32x4 *)(base + toff[i]);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid + 256 * i;
+            const int row = min(tile * TILE_ROWS + (p >> 3), P.S_cmp - 1);
+            stg[i] = *(const u32x4 *)(Kc + (int64_t)row * P.css + (p & 7) * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid + 256 * i;
+            const int row = p >> 3, pc = p & 7;
+            *(u32x4 *)(lds + buf * TILE_BYTES + row * ROWB + ((pc ^ ((row >> 1) & 7)) << 4)) = stg[i];
+        }
+    };
+    // K fragment of the 32-row half hf of a tile: row 32 hf + r, dims 16 s + 8 half .. (piece 2 s + half)
+    unsigned koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = (unsigned)(r * ROWB + (((2 * s + half) ^ ((r >> 1) & 7)) << 4));
+    auto load_kf = [&](int buf, int hf, x8 (&kf)[4]) {
+        const unsigned char *base = lds + buf * TILE_BYTES + hf * (32 * ROWB);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = *(const x8 *)(base + koff[s]);
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ================= sweep 1: row max and row sum per (query, head) column (per-lane online, exp2 domain) =================
+    float mrun[3], lrun[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        mrun[n] = -INFINITY;
+        lrun[n] = 0.f;
+    }
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+#ifdef SC32_NOSYNC  // ablation: no staging, no barriers (every tile reads buffer 0)
+        const int buf = 0;
+#else
+        const int buf = tile & 1;
+#endif
+#ifndef SC32_NOSYNC
+        if (tile + 1 < ntiles) load_tile(tile + 1);
+#endif
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const int rows_valid = P.S_cmp - tile * TILE_ROWS - 32 * hf;  // rows of this half >= this are padding
+            if (rows_valid <= 0) break;
+            x8 kf[4];
+            load_kf(buf, hf, kf);
+            f32x16 acc[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = zero16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[n] = SC32_MMA(kf[s], qf[n][s], acc[n]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                // common path (as in the 16x16 form): the lane keeps its reference max and only accumulates sum(exp2(x - m)); all 16 exponents
+                // are <= 12 whenever the sum stays <= 2^12, so the sum is the test; a larger (or inf / nan: m = -inf) sum or a padded half
+                // takes the exact slow path
+                // plain v_fma_f32 / v_add_f32, two partial sums (a packed fp32 op costs what its two halves cost: 4.9-5.8 against 2 x 2.6 cycles)
+                float s0 = 0.f, s1 = 0.f;
+                const float nm = -mrun[n];
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    s0 += SC32_EXP(__builtin_fmaf(acc[n][i], c2, nm));
+                    s1 += SC32_EXP(__builtin_fmaf(acc[n][i + 1], c2, nm));
+                }
+                float sum = s0 + s1;
+                if (__any(!(sum <= 4096.f)) || rows_valid < 32) {
+                    asm volatile("; sweep-1 slow path" ::: "memory");
+                    int rv = rows_valid;  // the row masks belong to this block
+                    asm volatile("" : "+s"(rv));
+                    float v[16];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = 8 * (i >> 2) + 4 * half + (i & 3);
+                        float a = acc[n][i];  // through an (empty) asm: keeps the masks, products and maxima of this rare path behind the branch
+                        asm volatile("" : "+v"(a));
+                        const float x = (row < rv) ? a * c2 : -INFINITY;
+                        v[i] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                    const float mnew = fmaxf(mrun[n], mx);
+                    sum = 0.f;
+                    if (mnew > -INFINITY) {  // a lane may see only padding rows
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(v[i] - mnew);
+                        lrun[n] = lrun[n] * __builtin_amdgcn_exp2f(mrun[n] - mnew);
+                        mrun[n] = mnew;
+                    }
+                }
+                lrun[n] += sum;
+            }
+        }
+#ifndef SC32_NOSYNC
+        if (tile + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+#endif
+    }
+    // merge the two lane halves of each column; m + log2(l) goes through LDS to the lanes that own the pair as a ROW in sweep 2
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const float m = xor32_max(mrun[n]);
+        float l = (mrun[n] > -INFINITY) ? lrun[n] * __builtin_amdgcn_exp2f(mrun[n] - m) : 0.f;
+        l = xor32_add(l);
+        if (half == 0) mlg[wave][32 * n + r] = -(m + __builtin_amdgcn_logf(l));  // p = exp2(s c2 + mlg)
+    }
+    wave_lds_fence();
+    // the 48 constants of a lane (rows 32 n + 8 gq + 4 half + e) are read from LDS where they are used: kept in registers they are the
+    // difference between 3 and 2 waves per SIMD (broadcast reads, 12 ds_read_b128 per half tile)
+    const float *ml_lane = &mlg[wave][4 * half];
+
+    // ================= sweep 2: normalise, Eq.10 head sum (in lane), Eq.9 stencil (along the lanes), store =================
+    const int l_sel = 4 * P.d_stride;
+    int jlast = P.S_sel - 1;  // last selection block this workgroup has to produce
+    if (P.causal_skip) {
+        const int t_last = min(t0 + QW, P.S) - 1;
+        jlast = min(jlast, (t_last + 1) / l_sel - 1);
+    }
+    const int nhalf2 = (jlast < 0) ? 0 : min(NH * ntiles, (4 * jlast + 3) / 32 + 1);  // 32-row halves (8 selection blocks each) to visit
+#ifdef SC32_SWEEP1  // ablation: first sweep only
+    const int tiles2 = 0;
+#else
+    const int tiles2 = (nhalf2 + NH - 1) / NH;
+#endif
+    // output: the 8 head-summed registers z of a half tile hold query tw + 4 (z >> 1) + (z & 1) + 2 half in this lane; lane r writes block
+    // 8 hfi + (r >> 2) when r & 3 == 0.  One scalar base per half tile + a 32-bit byte offset per register.
+    float *pg_b = P.p_grp + (int64_t)b * P.S * P.G * P.S_sel;
+    const unsigned poff = ((unsigned)(((tw + 2 * half) * P.G + g) * P.S_sel) + (unsigned)(r >> 2)) * 4u;  // register z = 0
+    const unsigned qstride = (unsigned)(P.G * P.S_sel) * 4u;                                               // bytes between consecutive queries
+    const bool all_rows = t0 + QW <= P.S;  // otherwise the stores check their query (last workgroup of a sequence)
+    float wprev[8];                        // x[-1] of lanes 0 / 32: lane 31 / 63 of the previous half tile
+#pragma unroll
+    for (int z = 0; z < 8; ++z) wprev[z] = 0.f;
+    const float halfw = 0.5f;
+    if (tiles2 > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int tile = 0; tile < tiles2; ++tile) {
+#ifdef SC32_NOSYNC  // ablation: no staging, no barriers (every tile reads buffer 0)
+        const int buf = 0;
+#else
+        const int buf = tile & 1;
+#endif
+#ifndef SC32_NOSYNC
+        if (tile + 1 < tiles2) load_tile(tile + 1);
+#endif
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const int hfi = NH * tile + hf;
+            if (hfi >= nhalf2) break;
+            x8 kf[4];
+            load_kf(buf, hf, kf);
+            f32x16 acc[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[n] = zero16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[n] = SC32_MMA(qf[n][s], kf[s], acc[n]);
+            // p of this lane's compressed key for its 48 (query, head) rows, as 12 chunks of 4 consecutive rows: chunk k = 4 n + gq
+            float p[12][4];
+            const float *mlp = ml_lane;
+            asm volatile("" : "+v"(mlp));  // (opaque: the loads stay inside the loop)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 mlv = *(const f32x4 *)(mlp + 32 * n + 8 * gq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[4 * n + gq][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[n][4 * gq + e], c2, mlv[e]));
+                }
+            const int cols_valid = P.S_cmp - 32 * hfi;
+            if (cols_valid < 32) {  // padded last half only (wave uniform): compressed keys past the end contribute nothing
+                int cv = cols_valid;
+                asm volatile("" : "+s"(cv));
+                const bool dead = r >= cv;
+#pragma unroll
+                for (int k = 0; k < 12; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (dead) p[k][e] = 0.f;
+            }
+            // Eq.10.  Rows of the wave in chunks of 4: the lower lane half owns the even chunks, the upper half the odd ones.  Per 6 chunks (24
+            // rows = 4 queries) and register triple (A, B, C) = chunks (3 m, 3 m + 1, 3 m + 2) of this half:
+            //   query 4m   = lower A[0..3]            + upper A[0..1]        query 4m+1 = lower B[0..3] + upper A[2..3]
+            //   query 4m+2 = upper B[0..3]            + lower C[0..1]        query 4m+3 = upper C[0..3] + lower C[2..3]
+            // so the lower half finishes 4m and 4m+1, the upper half 4m+2 and 4m+3, and two half swaps carry the 2-row parts.
+            float zs[8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float(&A)[4] = p[3 * m], (&Bc)[4] = p[3 * m + 1], (&C)[4] = p[3 * m + 2];
+                const float u = A[0] + A[1], v = A[2] + A[3], w = u + v;
+                const float sb = (Bc[0] + Bc[1]) + (Bc[2] + Bc[3]);
+                const float u2 = C[0] + C[1], v2 = C[2] + C[3], w2 = u2 + v2;
+                // swap(a, b): [0] = (lower a, lower b), [1] = (upper a, upper b)
+                const auto su = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u2), false, false);
+                const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v2), false, false);
+                float z1 = w + __uint_as_float(su[1]);   // lower half: query 4m
+                float z2 = sb + __uint_as_float(sv[1]);  // lower half: query 4m+1
+                // upper half (rows 2, 3 of the wave): query 4m+2 = sb + lower u2, query 4m+3 = w2 + lower v2
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf" : "+v"(z1) : "v"(__uint_as_float(su[0])), "v"(sb));
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf" : "+v"(z2) : "v"(__uint_as_float(sv[0])), "v"(w2));
+                zs[2 * m] = z1;
+                zs[2 * m + 1] = z2;
+            }
+            // Eq.9 along the lanes (lane = compressed key 32 hfi + r): block j = 8 hfi + r / 4 at lanes r % 4 == 0:
+            //   y = x[0] + x[1] + x[2] + 1/2 x[3] + 1/2 x[-1];  x[-1] of a row's first lane is lane 15 of the row before (row_bcast:15), of lanes
+            //   0 / 32 it is lane 31 / 63 of the previous half tile (kept rotated in wprev).
+            const bool mine = (r & 3) == 0 && 8 * hfi + (r >> 2) <= jlast;
+            float *pg_t = pg_b + 8 * hfi;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const float x = zs[z];
+                float y;
+                asm volatile(
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_fmac_f32_dpp %0, %1, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xe\n\t"
+                    "v_fmac_f32_dpp %0, %1, %2 row_bcast:15 row_mask:0xa bank_mask:0x1\n\t"
+                    "v_fmac_f32_dpp %0, %3, %2 quad_perm:[0,1,2,3] row_mask:0x5 bank_mask:0x1\n\t"
+                    : "=&v"(y)
+                    : "v"(x), "v"(halfw), "v"(wprev[z]));
+                // lane i <- lane i - 1 inside each 32-lane half (ds_swizzle rotate mode: no LDS memory, no address register)
+                wprev[z] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0xC000 | (1 << 10) | (1 << 5)));
+                if (mine && (all_rows || tw + 4 * (z >> 1) + (z & 1) + 2 * half < P.S)) *(float *)((char *)pg_t + (size_t)(4 * (z >> 1) + (z & 1)) * qstride + poff) = y;
+            }
+        }
+#ifndef SC32_NOSYNC
+        if (tile + 1 < tiles2) store_tile(buf ^ 1);
+        __syncthreads();
+#endif
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------
+bool scores_mfma32_supported(const ScoresMfmaParams &P, int Dk) {
+    // 32-bit byte offsets into one sequence's p_grp
+    return P.h == 6 && Dk == 64 && !P.big_out && (int64_t)P.S * P.G * P.S_sel * 4 < ((int64_t)1 << 32);
+}
+
+int launch_scores_mfma32(const ScoresMfmaParams &P, int dtype, hipStream_t st) {
+    dim3 grid((unsigned)((P.S + 63) / 64), (unsigned)(P.B * P.G));
+    if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((scores_mfma32_kernel<__bf16>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((scores_mfma32_kernel<_Float16>), grid, dim3(256), 0, st, P);
+    NSA_LAUNCH_CHECK("scores_mfma32");
+    return NSA_OK;
+}
+
+}  // namespace nsa

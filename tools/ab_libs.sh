@@ -5,7 +5,7 @@ set -u
 out=$1; shift; shift
 mkdir -p "$(dirname "$out")"
 IFS=$'\n' read -r -d '' -a cmds < <(printf '%s ' "$@" | sed 's/ ;; /\n/g' && printf '\0')
-for which in old new; do
+for which in ${AB_SET:-old new}; do
     cp "ab/$which.so" nsa_vibe_amd/libnsa_sel_hip.so
     for c in "${cmds[@]}"; do
         echo "== [$which] $c" >> "$out.$which.log"

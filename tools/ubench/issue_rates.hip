@@ -1,4 +1,4 @@
-// Issue-rate microbenchmark for gfx950 (run on the GPU box):  hipcc --offload-arch=gfx950 -O2 -o issue_rates issue_rates.hip && ./issue_rates
+// Issue-rate microbenchmark for gfx950 (run on the GPU box):  hipcc --offload-arch=gfx950 -O2 -mllvm -amdgpu-mfma-vgpr-form=1 -o issue_rates issue_rates.hip && ./issue_rates
 // Each kernel runs ITERS x UNROLL copies of one instruction pattern per wave; W waves per SIMD (one 256-thread workgroup = one wave per SIMD,
 // W workgroups per CU).  Reported: SIMD cycles per pattern instance = time x clock x (1 / (ITERS x UNROLL x W)), i.e. the reciprocal issue rate the
 // SIMD sustains with W waves to pick from.  Patterns: fma, pk_fma, exp, mfma 16x16x32 / 32x32x16 bf16, and MFMA + VALU mixes.
@@ -19,11 +19,11 @@ __global__ __launch_bounds__(256) void k(float *out) {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b0 = 1.0001f, c0 = 0.5f;
     f32x4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
-    f32x16 w0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, w1 = w0;
+    f32x16 w0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, w1 = w0, w2 = w0;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     f32x2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {1.0001f, 1.0001f}, pc = {0.5f, 0.5f};
-    bf16x8 fa, fb;
-    for (int i = 0; i < 8; ++i) { fa[i] = (__bf16)(float)(threadIdx.x & 7); fb[i] = (__bf16)1.0f; }
+    bf16x8 fa, fb, fb1, fb2;  // distinct B operands per accumulator chain (identical MFMAs would be merged by the compiler)
+    for (int i = 0; i < 8; ++i) { fa[i] = (__bf16)(float)(threadIdx.x & 7); fb[i] = (__bf16)1.0f; fb1[i] = (__bf16)(float)(i & 1); fb2[i] = (__bf16)(float)(threadIdx.x & 1); }
     for (int it = 0; it < ITERS; ++it) {
         if (PAT == 0) {  // 8 independent v_fma_f32
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -114,9 +114,117 @@ __global__ __launch_bounds__(256) void k(float *out) {
             asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0));
             m3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, m3, 0, 0, 0);
             asm volatile(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n") : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(c0));
+        } else if (PAT == 17) {  // 2 MFMA 32x32x16 + 32 pk_fma
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile(REP2(REP2("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n")) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile(REP2(REP2("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n")) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+        } else if (PAT == 18) {  // 32 pk_fma alone
+            asm volatile(REP2(REP2("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n")) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+            asm volatile(REP2(REP2("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n")) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+        } else if (PAT == 19) {  // 2 MFMA 32x32x16 + 32 asm volatile(REP2(REP2("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); adds
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile(REP2(REP2("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile(REP2(REP2("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (PAT == 20) {  // 32 asm volatile(REP2(REP2("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); adds alone
+            asm volatile(REP2(REP2("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            asm volatile(REP2(REP2("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %2, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %3, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (PAT == 21) {  // 2 MFMA 32x32x16 + 32 exp
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+            asm volatile(REP2(REP2("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+            asm volatile(REP2(REP2("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (PAT == 22) {  // 32 exp alone
+            asm volatile(REP2(REP2("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            asm volatile(REP2(REP2("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (PAT == 23) {  // burst + dependent VALU: 12 MFMA 32x32x16 (3 fresh accumulators x 4 k-steps), then 192 fma that read the 48 results
+            f32x16 z0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, z1 = z0, z2 = z0;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                z0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z0, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, z1, 0, 0, 0);
+                z2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb2, z2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(z0[i]), "v"(b0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(z1[i]), "v"(b0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(z2[i]), "v"(b0));
+                }
+        } else if (PAT == 24) {  // same, software-pipelined: the fmas read the results of the PREVIOUS iteration's burst
+            f32x16 z0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, z1 = z0, z2 = z0;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                z0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z0, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, z1, 0, 0, 0);
+                z2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb2, z2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(w0[i]), "v"(b0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(w1[i]), "v"(b0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(w2[i]), "v"(b0));
+                }
+            w0 = z0; w1 = z1; w2 = z2;
+        } else if (PAT == 25) {  // burst in CHAIN order: 3 x (4 dependent MFMA 32x32x16 back to back), then 192 fma on the results
+            f32x16 z0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, z1 = z0, z2 = z0;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) z0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, z0, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) z1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, z1, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) z2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb2, z2, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(z0[i]), "v"(b0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(z1[i]), "v"(b0));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a2) : "v"(z2[i]), "v"(b0));
+                }
+        } else if (PAT == 26) {  // ONE dependent chain of 16 v_fma_f32 (latency, not throughput)
+            asm volatile(REP8("v_fma_f32 %0, %0, %1, %2\n") REP8("v_fma_f32 %0, %0, %1, %2\n") : "+v"(a0) : "v"(b0), "v"(c0));
+        } else if (PAT == 27) {  // one dependent chain fma -> exp -> add, 5 times (15 instr)
+            asm volatile(REP2(REP2("v_fma_f32 %1, %0, %2, %3\n v_exp_f32 %1, %1\n v_add_f32 %0, %0, %1\n")) "v_fma_f32 %1, %0, %2, %3\n v_exp_f32 %1, %1\n v_add_f32 %0, %0, %1\n" : "+v"(a0), "+v"(a1) : "v"(b0), "v"(c0));
+        } else if (PAT == 28) {  // two independent chains of 8 v_fma_f32, interleaved
+            asm volatile(REP8("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n") : "+v"(a0), "+v"(a1) : "v"(b0), "v"(c0));
+        } else if (PAT == 29) {  // ONE chain of 4 dependent MFMA 32x32x16
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(w0) : "v"(fa), "v"(fb));
+        } else if (PAT == 30) {  // ONE chain of 4 dependent MFMA 16x16x32
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n" : "+v"(m0) : "v"(fa), "v"(fb));
+        } else if (PAT == 31) {  // three chains of 4 dependent MFMA 32x32x16, chain after chain (12 MFMA)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(w0) : "v"(fa), "v"(fb));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(w1) : "v"(fa), "v"(fb1));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(w2) : "v"(fa), "v"(fb2));
+        } else if (PAT == 32) {  // the same 12 MFMA, the three chains interleaved
+            asm volatile(REP2(REP2("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0\n v_mfma_f32_32x32x16_bf16 %1, %3, %5, %1\n v_mfma_f32_32x32x16_bf16 %2, %3, %6, %2\n")) : "+v"(w0), "+v"(w1), "+v"(w2) : "v"(fa), "v"(fb), "v"(fb1), "v"(fb2));
+        } else if (PAT == 15) {  // burst form: 12 MFMA 32x32x16 back to back (3 accumulators x 4 k-steps), then 192 fma
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+                w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+                w2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { asm volatile(REP2(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0)); }
+        } else if (PAT == 16) {  // the same 12 MFMA + 192 fma, one MFMA per 16 fma
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w0, 0, 0, 0);
+                { asm volatile(REP2(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0)); }
+                w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w1, 0, 0, 0);
+                { asm volatile(REP2(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0)); }
+                w2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, w2, 0, 0, 0);
+                { asm volatile(REP2(REP2("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n")) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(c0)); }
+            }
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + m0[0] + m1[1] + m2[2] + m3[3] + p0[0] + p1[1] + p2[0] + p3[1] + w0[0] + w1[5];
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + m0[0] + m1[1] + m2[2] + m3[3] + p0[0] + p1[1] + p2[0] + p3[1] + w0[0] + w1[5] + w2[7];
 }
 
 template <int PAT>
@@ -160,5 +268,23 @@ int main() {
     run<12>("2 x mfma32 + 8 x exp", 10, out, ghz, n);
     run<13>("2 x mfma32 + 32 x fma", 34, out, ghz, n);
     run<14>("4 x mfma16 + 32 x fma", 36, out, ghz, n);
+    run<15>("burst: 12 x mfma32, then 192 x fma", 204, out, ghz, n);
+    run<16>("12 x (mfma32 + 16 x fma)", 204, out, ghz, n);
+    run<23>("burst 12 x mfma32, then 192 x fma on results", 204, out, ghz, n);
+    run<24>("same, fmas on the previous burst", 204, out, ghz, n);
+    run<25>("chain-order burst (3 x 4 dependent), then fma", 204, out, ghz, n);
+    run<26>("one chain of 16 dependent fma", 16, out, ghz, n);
+    run<27>("one chain 5 x (fma -> exp -> add)", 15, out, ghz, n);
+    run<28>("two chains of 8 dependent fma", 16, out, ghz, n);
+    run<29>("one chain of 4 dependent mfma32", 4, out, ghz, n);
+    run<30>("one chain of 4 dependent mfma16", 4, out, ghz, n);
+    run<31>("3 chains x 4 dependent mfma32, chain after chain", 12, out, ghz, n);
+    run<32>("3 chains x 4 mfma32, interleaved", 12, out, ghz, n);
+    run<17>("2 x mfma32 + 32 x pk_fma", 34, out, ghz, n);
+    run<18>("32 x pk_fma", 32, out, ghz, n);
+    run<19>("2 x mfma32 + 32 x add_dpp", 34, out, ghz, n);
+    run<20>("32 x add_dpp", 32, out, ghz, n);
+    run<21>("2 x mfma32 + 32 x exp", 34, out, ghz, n);
+    run<22>("32 x exp", 32, out, ghz, n);
     return 0;
 }
