@@ -120,8 +120,9 @@ def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, 
     """Fused A2+A3+A4: Q [B,S,G,h,Dk], K_cmp [B,G,S_cmp,Dk] -> p_grp [B,S,G,S_sel] fp32 without
     materialising p_cmp (nsa_attention.py:1073-1091 in one call).
 
-    causal_skip=True returns 0 for the blocks neither selector can pick at row t ((j+1) l' > t+1; both mask
-    them to -inf, selection_scorer.py:156,276-280) instead of computing them; with leave_skipped=True those entries are left
+    causal_skip=True does not compute the blocks neither selector can pick at row t ((j+1) l' > t+1; both mask
+    them to -inf, selection_scorer.py:156,276-280): such an entry holds 0 or, where its workgroup computed the block for a later row, the
+    full value; with leave_skipped=True those entries are left
     uninitialised (no zero fill of the tensor) -- for results that go straight to the selectors.  variant: 0 auto, 1 generic
     (any dtype/geometry, query-chunked), 2 the MFMA kernel (bf16/f16, default block geometry)."""
     dev = _need_gpu(Q_all, K_cmp)

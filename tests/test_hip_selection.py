@@ -576,6 +576,44 @@ def test_flat_scorer_matches_four_tile_form(nv, tune, S, B):
     assert torch.equal(out[0][:, keep], out[1][:, keep])
 
 
+@pytest.mark.parametrize("S,B,dt", [(70, 1, "bf16"), (100, 3, "f16"), (777, 2, "bf16"), (4096, 2, "f16"), (16500, 1, "bf16")])
+def test_scorer_on_32x32_tiles_matches_the_16x16_form(nv, tune, S, B, dt):
+    """h = 6, D = 64: the 32x32x16 scorer (16 queries per wave; second sweep with a lane per compressed key: head sum in the lane, stencil along
+    the lanes) against the four-tile 16x16x32 form -- the same logits and exponentials; the six head terms and the five taps are added in a
+    different order (fp32 rounding of sums <= 6).  Lengths that end inside a 64-query workgroup, inside a 32-row half tile and before the
+    first full selection block are part of the set."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = torch.randn(B, S, 2, 6, 64, device="cuda", generator=g).to(tdt)
+    Kc = torch.randn(B, 2, meta.S_cmp, 64, device="cuda", generator=g).to(tdt)
+    Kc[:, :, ::7] *= 3.0  # a few dominant compressed tokens: the first sweep has to raise its reference maximum along the way
+    out = {}
+    for form in (0, 2):
+        tune("SCORES_FORM", form)
+        out[form] = nv.selection_scores(Q, Kc, meta, 0.125, variant=2)           # (variant 2: the MFMA kernels also for the short lengths)
+        out[form, "skip"] = nv.selection_scores(Q, Kc, meta, 0.125, causal_skip=True, variant=2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[2]).all()
+    assert (out[0] - out[2]).abs().max().item() <= 4e-6
+    # with the causal skip every block a selector may read at row t ((j + 1) l' <= t + 1) holds the full result; the others hold 0 or the full
+    # result (the skip is per workgroup: 32 queries in the 16x16 forms, 64 here)
+    tt = torch.arange(S, device="cuda")[:, None]
+    jj = torch.arange(meta.S_sel, device="cuda")[None, :]
+    readable = ((jj + 1) * 64 <= tt + 1)[None, :, None, :].expand_as(out[2])
+    for form in (0, 2):
+        sk, full = out[form, "skip"], out[form]
+        assert torch.equal(sk[readable], full[readable])
+        assert ((sk[~readable] == 0) | (sk[~readable] == full[~readable])).all()
+    # every row is a sum of h softmax rows pushed through Eq.9: it adds up to h (up to the mass of taps that fall off the block grid: none here)
+    t = S - 1
+    full = out[2][:, t].sum(-1)
+    assert (full - 6.0).abs().max().item() <= 1e-4
+
+
 @pytest.mark.parametrize("geom", [(32, 16, 64), (16, 16, 32)])
 def test_fused_decode_with_a_meta_from_before_the_first_compressed_token(nv, tune, geom):
     """a cache whose meta was built while S < l has an EMPTY Eq.9 map (no CSC entries at all) although K_cmp already holds its first token:
