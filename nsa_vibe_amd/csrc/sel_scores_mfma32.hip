@@ -6,11 +6,11 @@
 //
 // Cost model (tools/ubench/issue_rates.hip, profiles/r03/issue_rates.txt and scorer_notes.txt; cycles of one SIMD at the nominal clock, two or
 // more waves to pick from): v_fma / v_add / v_mul 2.6, v_pk_fma_f32 4.9-5.8 (two plain ops cost the same), DPP add 4.2, v_exp_f32 8.2,
-// MFMA 32x32x16 35.8, MFMA 16x16x32 19.5 (9 % more per flop).  Matrix and vector instructions of a SIMD do NOT run side by side to any
+// MFMA 32x32x16 33, MFMA 16x16x32 16.3 (the same per flop).  Matrix and vector instructions of a SIMD do NOT run side by side to any
 // useful degree, whatever the tile shape, the number of resident waves (2 or 3) or their relative phase: with 3 of the 4 k-steps removed this
 // kernel loses exactly the time of the removed MFMAs, with v_exp_f32 replaced by a multiply exactly the difference of their costs.  The time
 // of a scorer is the SUM of its instruction costs; this form is the one with the smallest sum found:
-// * 32x32x16 tiles: 9 % less matrix time for the same flops, half the LDS reads per query.
+// * 32x32x16 tiles: the same matrix time, half the LDS reads per query, and 16 accumulator registers of a lane in ONE row or column group.
 // * One wave = 16 queries = 96 (query, head) pairs = three 32-wide tiles, no idle column; one workgroup = 4 waves = 64 queries sharing the
 //   K_cmp tile in LDS.
 // * Sweep 1 (row max / row sum): S^T = K_cmp tile [32 x D] . Q^T [D x 32]: compressed keys are the MFMA rows, a lane owns ONE (query, head)
