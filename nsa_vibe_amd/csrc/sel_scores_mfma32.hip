@@ -17,12 +17,14 @@
 //   column per tile, so the running reference max and sum are one register each per tile.  Per logit: v_fma, v_exp, v_add.
 // * Sweep 2 (normalise, Eq.10 head sum, Eq.9 stencil, store): the operands swap, S = Q [32 x D] . K_cmp^T [D x 32]: a lane owns one
 //   COMPRESSED KEY (column) and 16 (query, head) rows per tile.  The head sum is then plain adds inside the lane (the 6 rows of a query are
-//   4 + 2 registers of the two lane halves: two v_permlane32_swap per 4 queries carry the 2-row parts across), and the stencil runs along the
-//   lanes on the head-summed value: 6 DPP operations per (query, 8 selection blocks) instead of a stencil per head and 17 DPP adds per 12
-//   logits for the head sum.
+//   4 + 2 registers of the two lane halves: two v_permlane32_swap per 4 queries carry the 2-row parts across), and the stencil runs on the
+//   head-summed value -- once per query instead of once per head -- with its lane movement done by the LDS: the 8 sums of a lane are written
+//   as [query][column] rows, read back as one ds_read_b128 (the 4 columns of a block) + one ds_read_b32 (column 4j - 1) per (query, block),
+//   and 4 plain ops finish Eq.9.  LDS instructions issue beside the vector pipe (LDS ~30 % busy here), DPP ones on it: 6 DPP operations per
+//   (query, 8 blocks) measured 13.8 ms at 64k x 16 where this form measures 13.3 (same box).
 //   The summation order differs from the 16x16 form (heads first, then taps): same fp32 arithmetic, last-bit differences.
 // Per 32 compressed rows x 96 pairs and wave: sweep 1 = 12 MFMA + 48 x (fma, exp, add) ~ 1,100 cycles, sweep 2 = 12 MFMA + 48 x (fma, exp) +
-// ~60 head-sum + 48 stencil operations ~ 1,380; floor of the two-sweep algorithm (MFMA + exp + one fma per logit, nothing else) ~ 950 each.
+// ~60 head-sum + 8 stencil operations ~ 1,200; floor of the two-sweep algorithm (MFMA + exp + one fma per logit, nothing else) ~ 950 each.
 // Ablation switches (timing only, results meaningless; tools/ablate_scorer.sh): SC32_KSTEPS=n keeps n of the 4 k-steps, SC32_NOEXP replaces
 // v_exp_f32 by a multiply, SC32_NOSYNC drops staging and barriers, SC32_SWEEP1 stops after the first sweep.
 #include "sel_scores_mfma.hpp"
@@ -67,6 +69,9 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
     constexpr int QPW = 16, QW = 64;  // queries per wave / workgroup
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float mlg[4][96];
+    // Eq.9 staging, per wave 16 rows (8 head-summed registers x 2 lane halves) of a 64-column ring (two half tiles) behind a 4-float lead;
+    // row stride 80 floats: the 16 (query, block) windows a quarter wave reads with one ds_read_b128 cover the 64 banks exactly once
+    __shared__ __attribute__((aligned(16))) float stn[4][16][80];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,16 +249,23 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
 #else
     const int tiles2 = (nhalf2 + NH - 1) / NH;
 #endif
-    // output: the 8 head-summed registers z of a half tile hold query tw + 4 (z >> 1) + (z & 1) + 2 half in this lane; lane r writes block
-    // 8 hfi + (r >> 2) when r & 3 == 0.  One scalar base per half tile + a 32-bit byte offset per register.
     float *pg_b = P.p_grp + (int64_t)b * P.S * P.G * P.S_sel;
-    const unsigned poff = ((unsigned)(((tw + 2 * half) * P.G + g) * P.S_sel) + (unsigned)(r >> 2)) * 4u;  // register z = 0
-    const unsigned qstride = (unsigned)(P.G * P.S_sel) * 4u;                                               // bytes between consecutive queries
     const bool all_rows = t0 + QW <= P.S;  // otherwise the stores check their query (last workgroup of a sequence)
-    float wprev[8];                        // x[-1] of lanes 0 / 32: lane 31 / 63 of the previous half tile
+    // Eq.9 through LDS (no VALU work for the lane movement: LDS instructions issue beside the vector pipe).  The 8 head-summed registers of a
+    // half tile are written as rows [register z + 8 half][column]; lane r then reads, for register z' = 4 rd + (r & 3) (rd = 0, 1) and block
+    // jb = r >> 2, the four columns of the block with one ds_read_b128 and column 4 jb - 1 with a ds_read_b32 -- the ring of two half tiles
+    // makes the last column of the previous half tile the natural neighbour of the first.
+    float *st_w = &stn[wave][8 * half][0];
+    const int q4 = r & 3, jb = r >> 2;
+    unsigned poff2[2];  // byte offset of (query of register 4 rd + q4, block jb) in the sequence's p_grp
+    bool row_ok[2];
 #pragma unroll
-    for (int z = 0; z < 8; ++z) wprev[z] = 0.f;
-    const float halfw = 0.5f;
+    for (int rd = 0; rd < 2; ++rd) {
+        const int t = tw + 4 * (2 * rd + (q4 >> 1)) + (q4 & 1) + 2 * half;
+        row_ok[rd] = t < P.S;
+        poff2[rd] = ((unsigned)((min(t, P.S - 1) * P.G + g) * P.S_sel) + (unsigned)jb) * 4u;
+    }
+    if (lane < 16) stn[wave][lane][4 + 63] = 0.f;  // column -1 of the first half tile: outside [0, S_cmp), dropped
     if (tiles2 > 0) {
         load_tile(0);
         store_tile(0);
@@ -327,28 +339,26 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                 zs[2 * m] = z1;
                 zs[2 * m + 1] = z2;
             }
-            // Eq.9 along the lanes (lane = compressed key 32 hfi + r): block j = 8 hfi + r / 4 at lanes r % 4 == 0:
-            //   y = x[0] + x[1] + x[2] + 1/2 x[3] + 1/2 x[-1];  x[-1] of a row's first lane is lane 15 of the row before (row_bcast:15), of lanes
-            //   0 / 32 it is lane 31 / 63 of the previous half tile (kept rotated in wprev).
-            const bool mine = (r & 3) == 0 && 8 * hfi + (r >> 2) <= jlast;
-            float *pg_t = pg_b + 8 * hfi;
+            {
+                const int par = hfi & 1;
 #pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                const float x = zs[z];
-                float y;
-                asm volatile(
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %0, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                    "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                    "v_fmac_f32_dpp %0, %1, %2 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                    "v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xe\n\t"
-                    "v_fmac_f32_dpp %0, %1, %2 row_bcast:15 row_mask:0xa bank_mask:0x1\n\t"
-                    "v_fmac_f32_dpp %0, %3, %2 quad_perm:[0,1,2,3] row_mask:0x5 bank_mask:0x1\n\t"
-                    : "=&v"(y)
-                    : "v"(x), "v"(halfw), "v"(wprev[z]));
-                // lane i <- lane i - 1 inside each 32-lane half (ds_swizzle rotate mode: no LDS memory, no address register)
-                wprev[z] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0xC000 | (1 << 10) | (1 << 5)));
-                if (mine && (all_rows || tw + 4 * (z >> 1) + (z & 1) + 2 * half < P.S)) *(float *)((char *)pg_t + (size_t)(4 * (z >> 1) + (z & 1)) * qstride + poff) = y;
+                for (int z = 0; z < 8; ++z) st_w[80 * z + 4 + 32 * par + r] = zs[z];
+                wave_lds_fence();
+                const bool mine = 8 * hfi + jb <= jlast;
+                float *pg_t = pg_b + 8 * hfi;
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const float *row = st_w + 80 * (4 * rd + q4);
+                    const f32x4 x = *(const f32x4 *)(row + 4 + 32 * par + 4 * jb);
+                    const float xm1 = row[4 + ((32 * par + 4 * jb + 63) & 63)];
+                    // (1/2 x[-1] + x[0]) + x[1] + x[2] + 1/2 x[3]: the order of the 16x16 form, on head sums
+                    float y = __builtin_fmaf(0.5f, xm1, x[0]);
+                    y += x[1];
+                    y += x[2];
+                    y = __builtin_fmaf(0.5f, x[3], y);
+                    if (mine && (all_rows || row_ok[rd])) *(float *)((char *)pg_t + poff2[rd]) = y;
+                }
+                wave_lds_fence();  // the next half tile overwrites the other half of the ring only after these reads
             }
         }
 #ifndef SC32_NOSYNC
