@@ -738,7 +738,7 @@ def main():
                             "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
                                     "so the stages can sum to slightly more.  The step is three launches: scores, select, attention"}
         flops_sc = 2.0 * B * S * G * H * meta.S_cmp * D
-        out["roofline_scores"] = {"kernel": "scores_mfma_kernel (fused p_cmp softmax + Eq.9 + Eq.10)", "bound": "mfma",
+        out["roofline_scores"] = {"kernel": "scores_mfma32_kernel (fused p_cmp softmax + Eq.10 + Eq.9 on 32x32x16 tiles; 16x16 forms for other group sizes)", "bound": "mfma",
                                   "achieved": flops_sc / (t_sc * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": flops_sc / (t_sc * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "kernel_ms": t_sc,
                                   "note": "algorithmic flops 2*B*S*heads*S_cmp*Dk (one pass; the kernel sweeps K_cmp twice because the "
