@@ -20,7 +20,7 @@
 //   4 + 2 registers of the two lane halves: two v_permlane32_swap per 4 queries carry the 2-row parts across), and the stencil runs on the
 //   head-summed value -- once per query instead of once per head -- with its lane movement done by the LDS: the 8 sums of a lane are written
 //   as [query][column] rows, read back as one ds_read_b128 (the 4 columns of a block) + one ds_read_b32 (column 4j - 1) per (query, block),
-//   and 4 plain ops finish Eq.9.  LDS instructions issue beside the vector pipe (LDS ~30 % busy here), DPP ones on it: 6 DPP operations per
+//   and 4 plain ops finish Eq.9; the stores go out per two half tiles, 64 aligned bytes per query and instruction.  LDS instructions issue beside the vector pipe (LDS ~30 % busy here), DPP ones on it: 6 DPP operations per
 //   (query, 8 blocks) measured 13.8 ms at 64k x 16 where this form measures 13.3 (same box).
 //   The summation order differs from the 16x16 form (heads first, then taps): same fp32 arithmetic, last-bit differences.
 // Per 32 compressed rows x 96 pairs and wave: sweep 1 = 12 MFMA + 48 x (fma, exp, add) ~ 1,100 cycles, sweep 2 = 12 MFMA + 48 x (fma, exp) +
@@ -69,9 +69,8 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
     constexpr int QPW = 16, QW = 64;  // queries per wave / workgroup
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float mlg[4][96];
-    // Eq.9 staging, per wave 16 rows (8 head-summed registers x 2 lane halves) of a 64-column ring (two half tiles) behind a 4-float lead;
-    // row stride 80 floats: the 16 (query, block) windows a quarter wave reads with one ds_read_b128 cover the 64 banks exactly once
-    __shared__ __attribute__((aligned(16))) float stn[4][16][80];
+    // Eq.9 staging, per wave 16 rows (8 head-summed registers x 2 lane halves) of a 128-column ring (four half tiles = two output pairs)
+    __shared__ __attribute__((aligned(16))) float stn[4][16][128];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -252,20 +251,17 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
     float *pg_b = P.p_grp + (int64_t)b * P.S * P.G * P.S_sel;
     const bool all_rows = t0 + QW <= P.S;  // otherwise the stores check their query (last workgroup of a sequence)
     // Eq.9 through LDS (no VALU work for the lane movement: LDS instructions issue beside the vector pipe).  The 8 head-summed registers of a
-    // half tile are written as rows [register z + 8 half][column]; lane r then reads, for register z' = 4 rd + (r & 3) (rd = 0, 1) and block
-    // jb = r >> 2, the four columns of the block with one ds_read_b128 and column 4 jb - 1 with a ds_read_b32 -- the ring of two half tiles
-    // makes the last column of the previous half tile the natural neighbour of the first.
+    // half tile are written as rows [register z + 8 half][column mod 128].  After every second half tile (64 columns = 16 blocks) lane r
+    // reads, for register z' = 2 rd + (r >> 4) (rd = 0 .. 3) and block jb = r & 15 of the pair, the four columns of the block with one
+    // ds_read_b128 and column 4 jb - 1 with a ds_read_b32 (the ring makes the last column of the previous pair the neighbour of the first), and
+    // stores: 16 consecutive lanes write the 64 contiguous, 64-byte aligned bytes of one query (8-block runs per half tile were 32 bytes and
+    // left the L2 with half-written sectors: 6.0 GB of writes for 4.3 GB of scores at 64k x 16).
     float *st_w = &stn[wave][8 * half][0];
-    const int q4 = r & 3, jb = r >> 2;
-    unsigned poff2[2];  // byte offset of (query of register 4 rd + q4, block jb) in the sequence's p_grp
-    bool row_ok[2];
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        const int t = tw + 4 * (2 * rd + (q4 >> 1)) + (q4 & 1) + 2 * half;
-        row_ok[rd] = t < P.S;
-        poff2[rd] = ((unsigned)((min(t, P.S - 1) * P.G + g) * P.S_sel) + (unsigned)jb) * 4u;
-    }
-    if (lane < 16) stn[wave][lane][4 + 63] = 0.f;  // column -1 of the first half tile: outside [0, S_cmp), dropped
+    const int q2 = r >> 4, jb = r & 15;
+    // query of (rd, this lane) = tw + 4 rd + q2 + 2 half: byte offset of its block jb in the sequence's p_grp for rd = 0, then a uniform stride
+    const unsigned poff0 = ((unsigned)(((tw + q2 + 2 * half) * P.G + g) * P.S_sel) + (unsigned)jb) * 4u;
+    const unsigned rdstride = (unsigned)(4 * P.G * P.S_sel) * 4u;
+    if (lane < 16) stn[wave][lane][127] = 0.f;  // column -1 of the first half tile: outside [0, S_cmp), dropped
     if (tiles2 > 0) {
         load_tile(0);
         store_tile(0);
@@ -340,25 +336,27 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                 zs[2 * m + 1] = z2;
             }
             {
-                const int par = hfi & 1;
 #pragma unroll
-                for (int z = 0; z < 8; ++z) st_w[80 * z + 4 + 32 * par + r] = zs[z];
+                for (int z = 0; z < 8; ++z) st_w[128 * z + 32 * (hfi & 3) + r] = zs[z];
                 wave_lds_fence();
-                const bool mine = 8 * hfi + jb <= jlast;
-                float *pg_t = pg_b + 8 * hfi;
+                if ((hfi & 1) || hfi == nhalf2 - 1) {  // a pair of half tiles is complete (or the sweep ends on a single one)
+                    const int pr = hfi >> 1, base = 64 * (pr & 1);
+                    const bool mine = 16 * pr + jb <= jlast;
+                    float *pg_t = pg_b + 16 * pr;
 #pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    const float *row = st_w + 80 * (4 * rd + q4);
-                    const f32x4 x = *(const f32x4 *)(row + 4 + 32 * par + 4 * jb);
-                    const float xm1 = row[4 + ((32 * par + 4 * jb + 63) & 63)];
-                    // (1/2 x[-1] + x[0]) + x[1] + x[2] + 1/2 x[3]: the order of the 16x16 form, on head sums
-                    float y = __builtin_fmaf(0.5f, xm1, x[0]);
-                    y += x[1];
-                    y += x[2];
-                    y = __builtin_fmaf(0.5f, x[3], y);
-                    if (mine && (all_rows || row_ok[rd])) *(float *)((char *)pg_t + poff2[rd]) = y;
+                    for (int rd = 0; rd < 4; ++rd) {
+                        const float *row = st_w + 128 * (2 * rd + q2);
+                        const f32x4 x = *(const f32x4 *)(row + base + 4 * jb);
+                        const float xm1 = row[(base + 4 * jb + 127) & 127];
+                        // (1/2 x[-1] + x[0]) + x[1] + x[2] + 1/2 x[3]: the order of the 16x16 form, on head sums
+                        float y = __builtin_fmaf(0.5f, xm1, x[0]);
+                        y += x[1];
+                        y += x[2];
+                        y = __builtin_fmaf(0.5f, x[3], y);
+                        if (mine && (all_rows || tw + 4 * rd + q2 + 2 * half < P.S)) *(float *)((char *)pg_t + (size_t)rd * rdstride + poff0) = y;
+                    }
+                    wave_lds_fence();  // the next pair overwrites the other half of the ring only after these reads
                 }
-                wave_lds_fence();  // the next half tile overwrites the other half of the ring only after these reads
             }
         }
 #ifndef SC32_NOSYNC
