@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 run() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -1; }
 run NSA_HIP_SEL_FLAT=1 NSA_HIP_SEL_FUSE=1
 run NSA_HIP_SEL_FLAT=0 NSA_HIP_SCORES_FORM=0 NSA_HIP_DECODE_STENCIL=0 NSA_HIP_SEL_ROWSUM=0
-run NSA_HIP_SEL_ROWS=1 NSA_HIP_DECODE_UNFUSED=1 NSA_HIP_DECODE_WG=0
+run NSA_HIP_SEL_ROWS=1 NSA_HIP_DECODE_UNFUSED=1 NSA_HIP_DECODE_WG=0 NSA_HIP_SCORES_FORM=1
 run NSA_HIP_SEL_ROWS=0 NSA_HIP_ATTN_STAGE=0 NSA_HIP_BAND_STAGE=0 NSA_HIP_ATTN_MAP=0
 run NSA_HIP_SEL_BLOCKS=2 NSA_HIP_DECODE_UNFUSED=0 NSA_HIP_ATTN_MAP=1
 run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0
