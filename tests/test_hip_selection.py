@@ -614,6 +614,31 @@ def test_scorer_on_32x32_tiles_matches_the_16x16_form(nv, tune, S, B, dt):
     assert (full - 6.0).abs().max().item() <= 1e-4
 
 
+def test_scorer_on_32x32_tiles_with_logits_far_apart(nv, orc, tune):
+    """logits spread over hundreds of units (one compressed token dominates a row, and which one changes along the sequence): the first sweep
+    has to raise its reference maximum in the middle of a tile, rows underflow everywhere else; against the oracle on the rounded inputs"""
+    import torch
+
+    S, B, G, h, D = 1500, 1, 2, 6, 64
+    rng = np.random.default_rng(77)
+    m = nv.build_block_meta(S, 32, 16, 64, 16, 512)
+    mo = orc.build_block_meta(S, 32, 16, 64, 16, 512)
+    Q = rng.standard_normal((B, S, G, h, D), dtype=np.float32) * 4.0
+    Kc = rng.standard_normal((B, G, m.S_cmp, D), dtype=np.float32) * 4.0
+    Kc[:, :, 37::41] *= 4.0
+    rd = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()  # noqa: E731
+    ref = orc.map_pcmp_to_pslc_and_pgrp(orc.compute_pcmp_all(rd(Q), rd(Kc), 1.0 / np.sqrt(D)), mo)[1]
+    err = {}
+    for form in (2, 0):
+        tune("SCORES_FORM", form)
+        got = nv.selection_scores(dev(Q, torch.bfloat16), dev(Kc, torch.bfloat16), m, variant=2).cpu().numpy()
+        assert np.isfinite(got).all()
+        err[form] = float(np.abs(got - ref).max())
+    print("max |p_grp - oracle|:", err)
+    # exponents of a few hundred carry an fp32 ulp of 3e-5 into the exponential: both forms sit at that level, neither above the other's
+    assert err[2] < 6e-5 and err[0] < 6e-5 and err[2] <= 2.0 * err[0] + 1e-6
+
+
 @pytest.mark.parametrize("geom", [(32, 16, 64), (16, 16, 32)])
 def test_fused_decode_with_a_meta_from_before_the_first_compressed_token(nv, tune, geom):
     """a cache whose meta was built while S < l has an EMPTY Eq.9 map (no CSC entries at all) although K_cmp already holds its first token:
