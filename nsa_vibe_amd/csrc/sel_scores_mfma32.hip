@@ -233,7 +233,6 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
     wave_lds_fence();
     // the 48 constants of a lane (rows 32 n + 8 gq + 4 half + e) are read from LDS where they are used: kept in registers they are the
     // difference between 3 and 2 waves per SIMD (broadcast reads, 12 ds_read_b128 per half tile)
-    const float *ml_lane = &mlg[wave][4 * half];
 
     // ================= sweep 2: normalise, Eq.10 head sum (in lane), Eq.9 stencil (along the lanes), store =================
     const int l_sel = 4 * P.d_stride;
@@ -248,7 +247,15 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
 #else
     const int tiles2 = (nhalf2 + NH - 1) / NH;
 #endif
+    // the scores of this sequence as a buffer: the stores take a 32-bit lane offset + a scalar offset (no 64-bit address arithmetic on the
+    // vector pipe), and rows past the end of the sequence fall outside the buffer
     float *pg_b = P.p_grp + (int64_t)b * P.S * P.G * P.S_sel;
+    const __amdgpu_buffer_rsrc_t pg_rs = [&] {
+        const uint64_t a = (uint64_t)pg_b;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                                 __builtin_amdgcn_readfirstlane((int)((unsigned)P.S * (unsigned)P.G * (unsigned)P.S_sel * 4u)), 0x00020000);
+    }();
     const bool all_rows = t0 + QW <= P.S;  // otherwise the stores check their query (last workgroup of a sequence)
     // Eq.9 through LDS (no VALU work for the lane movement: LDS instructions issue beside the vector pipe).  The 8 head-summed registers of a
     // half tile are written as rows [register z + 8 half][column mod 128].  After every second half tile (64 columns = 16 blocks) lane r
@@ -291,8 +298,9 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                 for (int n = 0; n < 3; ++n) acc[n] = SC32_MMA(qf[n][s], kf[s], acc[n]);
             // p of this lane's compressed key for its 48 (query, head) rows, as 12 chunks of 4 consecutive rows: chunk k = 4 n + gq
             float p[12][4];
-            const float *mlp = ml_lane;
-            asm volatile("" : "+v"(mlp));  // (opaque: the loads stay inside the loop)
+            int mlo = 4 * half;
+            asm volatile("" : "+v"(mlo));  // (an opaque OFFSET: the loads stay inside the loop and stay LDS reads -- an opaque pointer made them flat loads)
+            const float *mlp = &mlg[wave][mlo];
 #pragma unroll
             for (int n = 0; n < 3; ++n)
 #pragma unroll
@@ -342,7 +350,6 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                 if ((hfi & 1) || hfi == nhalf2 - 1) {  // a pair of half tiles is complete (or the sweep ends on a single one)
                     const int pr = hfi >> 1, base = 64 * (pr & 1);
                     const bool mine = 16 * pr + jb <= jlast;
-                    float *pg_t = pg_b + 16 * pr;
 #pragma unroll
                     for (int rd = 0; rd < 4; ++rd) {
                         const float *row = st_w + 128 * (2 * rd + q2);
@@ -353,7 +360,8 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                         y += x[1];
                         y += x[2];
                         y = __builtin_fmaf(0.5f, x[3], y);
-                        if (mine && (all_rows || tw + 4 * rd + q2 + 2 * half < P.S)) *(float *)((char *)pg_t + (size_t)rd * rdstride + poff0) = y;
+                        if (mine && (all_rows || tw + 4 * rd + q2 + 2 * half < P.S))
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), pg_rs, (int)poff0, (int)(64u * (unsigned)pr + (unsigned)rd * rdstride), 0);
                     }
                     wave_lds_fence();  // the next pair overwrites the other half of the ring only after these reads
                 }
