@@ -164,46 +164,90 @@ def attention_extremes(nv, device, iters=5):
     return out
 
 
-def decode_bench(nv, B, S_ctx, steps, device):
-    """Decode-shaped hot path: B sequences at context S_ctx, one new token each (sequential-mode selector,
-    preallocated K/V cache passed as a strided view -- no torch.cat append as in nsa/cache/kv_cache.py:28-30).
-    Returns tok/s, ms per step and the bytes one step must read (every one of them exactly once: the HBM roofline of decode)."""
-    meta, Q, Kc, K, V = make_inputs(nv, B, S_ctx, device, 7)
-    q1 = Q[:, -1:].contiguous()
-    del Q
-    t = S_ctx - 1
+COLD_BYTES_BETWEEN_USES = 512 * 2 ** 20  # bytes other cache sets load between two uses of one set's lines: twice the 256 MiB Infinity Cache
 
+
+def decode_cache_sets(nv, B, S_ctx, device, n_sets, seed=7):
+    """n_sets independent decode states (q, K_cmp, K, V) of B sequences at context S_ctx -- the layers of a model, each with its own cache and
+    its own query (so its own selected blocks).  Generated in bf16 on the device (no fp32 temporaries: K/V of B=256 @64k are 8 GiB per set)."""
+    meta = nv.build_block_meta(S_ctx, L_CMP, D_CMP, L_SEL, N_SEL, 512)
+    sets = []
+    for i in range(n_sets):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + 1009 * i)
+        mk = lambda *sh: torch.randn(*sh, device=device, generator=g, dtype=torch.bfloat16)  # noqa: E731
+        sets.append((mk(B, 1, G, H, D), mk(B, G, meta.S_cmp, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)))
+    return meta, sets
+
+
+def decode_step_bytes(B, S_ctx):
+    """bytes one decode step must read, each exactly once: sum_rows L_row*(Dk+Dv)*2 (selected K/V, L_row <= n*l') + B*G*S_cmp*Dk*2 (compressed keys)"""
+    S_cmp = (S_ctx - L_CMP) // D_CMP + 1
+    return B * G * (min(N_SEL * L_SEL, S_ctx) * (D + D) * 2 + S_cmp * D * 2)
+
+
+def decode_bench(nv, B, S_ctx, steps, device, max_sets=32):
+    """Decode-shaped hot path: B sequences at context S_ctx, one new token each (sequential-mode selector, preallocated K/V cache passed as a
+    strided view -- no torch.cat append as in nsa/cache/kv_cache.py:28-30), timed the way a model's decode loop issues it
+    (bench/bench_decode.py:123-136): steps back to back, each on ANOTHER layer's cache.
+
+    COLD (the figure the roofline uses): the steps rotate over n_sets independent (q, K_cmp, K, V) sets -- n_sets chosen so that the other
+    sets load >= 512 MiB between two uses of any line (twice the Infinity Cache; 12 sets at B=64 @16k, the layer count of m7c_125m), every
+    set with its own query, hence its own 13 scored blocks: every byte comes from HBM.  WARM (kept for the record; rounds 1-3 reported it):
+    the same set 20 times back to back -- the <= 201 MB a step touches then stay in the 256 MiB Infinity Cache."""
+    step_bytes = decode_step_bytes(B, S_ctx)
+    n_sets = min(max_sets, -(-COLD_BYTES_BETWEEN_USES // step_bytes) + 1)
+    meta, sets = decode_cache_sets(nv, B, S_ctx, device, n_sets)
+    t = S_ctx - 1
     O = torch.empty(B, 1, G, H, D, device=device, dtype=torch.bfloat16)
     rg = torch.empty(B, G, N_SEL, 2, device=device, dtype=torch.int32)
-
-    def step():  # scores -> sequential top-n -> attention in one native call (nsa_sel_decode_step)
-        return nv.selection_decode_step(q1, Kc, K, V, meta, N_SEL, t, out=O, ranges_out=rg)
-
-    # a decode loop issues its steps back to back: 20 steps between a pair of events, median over the batches.  (An event pair around every
-    # single call adds ~2.3 us of event handling to a 20 us step: reported as ms_per_step_single_call.)
     nb = 20
+    pos = [0]
 
-    def batch():
+    def cold_batch():  # scores -> sequential top-n -> attention in one native call (nsa_sel_decode_step) per step
         for _ in range(nb):
-            step()
+            q1, Kc, K, V = sets[pos[0] % n_sets]
+            pos[0] += 1
+            nv.selection_decode_step(q1, Kc, K, V, meta, N_SEL, t, out=O, ranges_out=rg)
 
-    ms_single = time_events(step, steps, warm=3)
-    ms = time_events(batch, max(3, steps // nb * 3), warm=1) / nb
-    L = float((rg[..., 1] - rg[..., 0]).clamp_min(0).sum().item())  # selected tokens over all (b,g) rows
+    def warm_batch():
+        q1, Kc, K, V = sets[0]
+        for _ in range(nb):
+            nv.selection_decode_step(q1, Kc, K, V, meta, N_SEL, t, out=O, ranges_out=rg)
+
+    nrep = max(3, steps // nb * 3)
+    ms_warm = time_events(warm_batch, nrep, warm=1) / nb
+    ms_cold = time_events(cold_batch, nrep, warm=1) / nb
+    Lsum = 0.0
+    for q1, Kc, K, V in sets:  # selected tokens over all (b,g) rows, mean over the sets
+        nv.selection_decode_step(q1, Kc, K, V, meta, N_SEL, t, out=O, ranges_out=rg)
+        Lsum += float((rg[..., 1] - rg[..., 0]).clamp_min(0).sum().item())
+    L = Lsum / n_sets
     gather_bytes = L * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V once per group (triton_sel_kernel/__init__.py:483)
     kcmp_bytes = float(B * G * meta.S_cmp * D * 2)  # the scorer reads every compressed key of every (b,g) once
-    return {"tok_per_s": B / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_single_call": ms_single, "steps_per_timed_batch": nb, "context": S_ctx, "batch": B, "selected_tokens_per_row": L / (B * G),
-            "gather_bytes": gather_bytes, "kcmp_bytes": kcmp_bytes, "kv_resident_bytes": float(2 * B * G * S_ctx * D * 2)}
+    between = (n_sets - 1) * (gather_bytes + kcmp_bytes)
+    del sets
+    torch.cuda.empty_cache()
+    return {"tok_per_s": B / (ms_cold * 1e-3), "ms_per_step": ms_cold, "ms_per_step_cold": ms_cold, "ms_per_step_warm": ms_warm,
+            "tok_per_s_warm": B / (ms_warm * 1e-3), "steps_per_timed_batch": nb, "context": S_ctx, "batch": B,
+            "cache_sets": n_sets, "bytes_loaded_between_two_uses_of_a_set": between, "cold": bool(between >= COLD_BYTES_BETWEEN_USES),
+            "selected_tokens_per_row": L / (B * G), "gather_bytes": gather_bytes, "kcmp_bytes": kcmp_bytes,
+            "kv_resident_bytes": float(n_sets * 2 * B * G * S_ctx * D * 2)}
 
 
 def decode_roofline(d, traffic):
-    """HBM roofline of one decode step: bytes that must be read once / step time vs the 8 TB/s peak"""
+    """HBM roofline of one decode step: bytes that must be read once / COLD step time vs the 8 TB/s peak"""
     alg = d["gather_bytes"] + d["kcmp_bytes"]
-    ach = alg / (d["ms_per_step"] * 1e-3) / 1e9
+    ach = alg / (d["ms_per_step_cold"] * 1e-3) / 1e9
+    ach_w = alg / (d["ms_per_step_warm"] * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+            "cold": d["cold"], "cache_sets": d["cache_sets"], "bytes_loaded_between_two_uses_of_a_set": d["bytes_loaded_between_two_uses_of_a_set"],
+            "warm_same_set_GBps": ach_w, "warm_same_set_frac_not_an_hbm_figure": ach_w / HBM_PEAK_GBPS,
             "algorithmic_bytes_per_step": alg, "gather_bytes": d["gather_bytes"], "kcmp_bytes": d["kcmp_bytes"],
-            "step_ms": d["ms_per_step"], "workload": f"decode step, B={d['batch']} sequences at context {d['context']} "
-            f"(K/V resident: {d['kv_resident_bytes'] / 2 ** 20:.0f} MiB), one native call (scores -> top-n -> attention)",
+            "step_ms": d["ms_per_step_cold"], "step_ms_warm": d["ms_per_step_warm"],
+            "workload": f"decode step, B={d['batch']} sequences at context {d['context']}, rotating over {d['cache_sets']} independent cache sets "
+            f"(K/V resident: {d['kv_resident_bytes'] / 2 ** 20:.0f} MiB; {d['bytes_loaded_between_two_uses_of_a_set'] / 2 ** 20:.0f} MiB loaded between two uses of a set), "
+            "one native call per step (scores -> top-n -> attention)",
             "formula": "sum_rows L_row*(Dk+Dv)*2 B + B*G*S_cmp*Dk*2 B, each read once (nsa_attention.py:634-635; "
                        "triton_sel_kernel/__init__.py:483)"}
 
@@ -381,7 +425,7 @@ def cpu_baseline(S, B, seed=3, min_seconds=10.0):
 def pmc_traffic(tag, key="traffic_bytes"):
     """HBM bytes per launch for a workload, measured with rocprofv3 PMC counters in separate passes (tools/pmc_traffic.sh) and
     committed under profiles/ (bench.py cannot run the profiler on itself); None if not measured."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             return float(json.load(open(os.path.join(ROOT, "profiles", rnd, f"traffic_{tag}.json")))[key])
         except (OSError, KeyError, ValueError, TypeError):
@@ -695,6 +739,9 @@ def main():
                    "global_batch": world * B, "seq_len": S, "parallelism": f"batch x group shard over {world} GPU(s), no collective"},
         "ranks": ranks,
     }
+    from nsa_vibe_amd import _lib as _nsa_lib
+
+    out["library"] = _nsa_lib.loaded_library()  # which build of libnsa_sel_hip.so ran (NSA_HIP_LIB can point at an A/B build: never the product figure)
     if rank == 0:
         t_sc, t_sel, t_att, t_sa, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
         gathered = n_tiles * BLK_KEYS * (D + D) * 2
@@ -702,9 +749,6 @@ def main():
         flops = 4.0 * H * Lsum * D  # 2*h*L*Dk (QK^T) + 2*h*L*Dv (PV) per row
         tfl = flops / (t_att * 1e-3) / 1e12
         traffic = pmc_traffic(f"S{S}_B{B}")
-        mfma = {"bound": "mfma", "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS,
-                "qk_frac": 0.5 * tfl / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
-                "note": "in-block QK^T + PV flops 4*h*L*D per row over the same kernel time: the matrix pipe is far from binding here"}
         l2 = {"bound": "l2", "achieved": gathered / (t_att * 1e-3) / 1e9, "peak": L2_PEAK_GBPS, "unit": "GB/s",
               "frac": gathered / (t_att * 1e-3) / 1e9 / L2_PEAK_GBPS, "gathered_bytes_per_launch": gathered,
               "note": "64-key K/V blocks really brought into LDS (the 8 rows of one wave share a block any of them selected) vs the "
@@ -720,20 +764,26 @@ def main():
                    "frac_of_measured_stream_rate": ach / 6290.0, "traffic": traffic,
                    "note": "HBM-side bytes of the attention launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE per the MI355X guide, "
                            "profiles/r03/traffic_*.json, same shape) / HIP-event time"}
-        # The contract's line (prompt section 4 / SURVEY 8(d)): bound "hbm", achieved = ALGORITHMIC bytes per launch (sum_rows L_row*(Dk+Dv)*2 B,
-        # the reference's own formula, triton_sel_kernel/__init__.py:483) / kernel time, peak = the 8 TB/s HBM figure, traffic = PMC bytes.  In
-        # prefill the K/V of a (b,g) are re-read ~S*n*l'/S_kv times by different rows and served by L2, so `achieved` exceeds the HBM peak
-        # (SURVEY 8(d) says so itself: "report raw rocprof HBM bytes next to it"): frac > 1 is that re-use, not a claim.  What really binds
-        # the launch is in the nested objects: `hbm_traffic` (PMC bytes / time: what still misses L2), `l2` (the 64-key blocks the waves bring
-        # into LDS / time against the guide's ~34.5 TB/s aggregate; the guide's measured L2 gather loop reaches 16.8-18.8 TB/s), `mfma`
-        # (in-block QK^T + PV flops against the dense bf16 peak).  The HBM-bound configuration of this path is decode: `decode_roofline`.
-        ach_alg = alg_bytes / (t_att * 1e-3) / 1e9
-        out["roofline"] = dict(common, bound="hbm", achieved=ach_alg, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach_alg / HBM_PEAK_GBPS,
-                               note="achieved = algorithmic gather bytes (sum_rows L_row*256 B, SURVEY 8(d)) / HIP-event time of the attention launches; "
-                                    "above the HBM peak because rows re-read K/V out of L2 (frac > 1 = cache re-use).  Binding side: see `l2` "
-                                    "(gathered 64-key blocks through L2 -> LDS) and `hbm_traffic` (PMC); decode (`decode_roofline`) is the "
-                                    "HBM-bound configuration",
-                               hbm_traffic=hbm, l2=l2, mfma=mfma)
+        # Top level = the roof SURVEY 8(d) names for the timed (prefill) form of this kernel: the in-block QK^T / PV GEMMs against the dense
+        # bf16 MFMA peak (2*h*L*Dk + 2*h*L*Dv flop per row, triton_sel_kernel/__init__.py:483 counts the same L), a fraction <= 1.  The
+        # memory-side views sit beside it, nested AND as scalar keys (so they survive a parser that keeps scalars only): `hbm_traffic_frac` =
+        # PMC HBM bytes / time against 8 TB/s, `l2_frac` = the 64-key blocks the waves really bring into LDS / time against the guide's
+        # ~34.5 TB/s aggregate.  The ALGORITHMIC gather rate of 8(d) (sum_rows L_row*256 B / time) exceeds the HBM peak in prefill because the
+        # rows of a (b,g) re-read its K/V out of L2 -- it is a plain field (`algorithmic_gather_GBps`), never a fraction.  The HBM-bound
+        # configuration of this path is decode: `decode_roofline`.
+        out["roofline"] = dict(common, bound="mfma", achieved=tfl, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=tfl / MFMA_BF16_PEAK_TFLOPS,
+                               qk_frac=0.5 * tfl / MFMA_BF16_PEAK_TFLOPS, algorithmic_flops_per_launch=flops,
+                               hbm_traffic_frac=(hbm["frac"] if hbm else None), hbm_traffic_GBps=(hbm["achieved"] if hbm else None),
+                               l2_frac=l2["frac"], l2_gathered_GBps=l2["achieved"],
+                               note="achieved = in-block QK^T + PV flops (4*h*L*D per row, SURVEY 8(d)) / HIP-event time of the attention launches "
+                                    "vs the dense bf16 MFMA peak; qk_frac = the QK^T half (north_star's target names it).  Memory side: "
+                                    "hbm_traffic (PMC bytes / time vs 8 TB/s), l2 (gathered 64-key blocks through L2 -> LDS vs ~34.5 TB/s); "
+                                    "algorithmic_gather_GBps is the 8(d) byte formula / time (above the HBM peak: L2 re-use), not a fraction",
+                               hbm_traffic=hbm, l2=l2)
+        for key in ("frac", "hbm_traffic_frac", "l2_frac"):
+            v = out["roofline"][key]
+            if v is not None and not (0.0 <= v <= 1.0):
+                raise SystemExit(f"bench.py: roofline.{key} = {v} is not a fraction of its roof; refusing to print the line")
         out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att, "select_and_attention_one_call": t_sa,
                             "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
                                     "so the stages can sum to slightly more.  The step is three launches: scores, select, attention"}
@@ -748,14 +798,19 @@ def main():
         if not args.no_extra and world == 1:
             extra = {}
             try:
-                for Bd, Sd in ((64, 16384), (128, 16384), (256, 16384), (64, 65536), (1, 65536)):
+                # BASELINE metric: decode tok/s at S in {4k, 16k, 64k}; every figure COLD (rotating cache sets, decode_bench); the top-level
+                # decode_roofline is the S = 65536 configuration (north_star's length) with the highest cold fraction
+                best = None
+                for Bd, Sd in ((64, 4096), (256, 4096), (64, 16384), (128, 16384), (256, 16384), (64, 65536), (128, 65536), (256, 65536), (1, 65536)):
                     d = decode_bench(nv, Bd, Sd, 30, device)
                     extra[f"decode_B{Bd}_S{Sd}"] = d
-                    rl = decode_roofline(d, pmc_traffic(f"decode_B{Bd}_S{Sd}"))
-                    if Bd == 64 and Sd == 16384:
-                        out["decode_roofline"] = rl
-                    else:
-                        extra[f"decode_roofline_B{Bd}_S{Sd}"] = rl
+                    rl = decode_roofline(d, pmc_traffic(f"decode_cold_B{Bd}_S{Sd}"))
+                    extra[f"decode_roofline_B{Bd}_S{Sd}"] = rl
+                    if Sd == 65536 and rl["cold"] and (best is None or rl["frac"] > best["frac"]):
+                        best = rl
+                if best is not None:
+                    out["decode_roofline"] = best
+                out["decode_tok_per_s_cold"] = {k[7:]: v["tok_per_s"] for k, v in extra.items() if k.startswith("decode_B")}
                 for S2, B2 in ((4096, 8), (4096, 1), (16384, 1), (65536, 1)):
                     m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
                     ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 5, warm=2)

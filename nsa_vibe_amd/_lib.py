@@ -91,6 +91,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_loaded_path = None
 
 
 def build(verbose: bool = False) -> str:
@@ -104,13 +105,17 @@ def build(verbose: bool = False) -> str:
 
 def lib():
     """Load the C-ABI library (once).  Raises ImportError if it has not been built."""
-    global _lib
+    global _lib, _loaded_path
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # NSA_HIP_LIB: measurement aid only -- another BUILD of this library (an A/B pair, a TIMELINE or ablation build under ab/, see
+        # csrc/Makefile) is loaded in place of the product without ever being copied over it; bench.py and smoke() print which file ran
+        path = os.environ.get("NSA_HIP_LIB") or LIB_PATH
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} not found: the HIP extension is required (no fallback path exists). "
+                f"{path} not found: the HIP extension is required (no fallback path exists). "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C nsa_vibe_amd/csrc`.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
+        _loaded_path = os.path.abspath(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
@@ -119,6 +124,16 @@ def lib():
             raise ImportError("libnsa_sel_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+def loaded_library() -> dict:
+    """path and sha256 (first 16 hex digits) of the library this process runs on: recorded by bench.py and smoke()"""
+    import hashlib
+
+    lib()
+    with open(_loaded_path, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"path": os.path.relpath(_loaded_path, os.path.dirname(_HERE)), "sha16": sha, "product": _loaded_path == os.path.abspath(LIB_PATH)}
 
 
 def set_tuning(name: str, value: int) -> None:

@@ -61,8 +61,15 @@ static size_t dstep_lds(int nw) { return (size_t)nw * DEC_ATT_TILE + DSTEP_TAIL 
 // forced blocks have landed, moving that traffic back onto the critical path)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename T, int NW, bool SPLIT, int HC>
+// CPW = chunks of 64 compressed rows per wave.  2: the logits of both stay in the MFMA accumulators (contexts to 32 NW chunks).  4 (round 4,
+// unsplit only): a row of up to 4 NW chunks in ONE workgroup -- 64k contexts on 16 waves, 32k on 8 -- for batches whose rows times a team's
+// workgroups do not fit the chip together (B >= 128 at 64k: a team must be co-resident, R NS <= slots): the first chunk's logits stay in
+// registers, those of the later three wait in LDS ([slot][u][head][q] f32x4, 256 h bytes per chunk: each lane reads back exactly what it
+// wrote, so no barrier guards them) until the row's log-sum-exp is known.  Two chunks (16 KiB per wave) are in flight throughout.  Same
+// arithmetic on the same values: p_grp, ranges and O have the bits of every other form.
+template <typename T, int NW, bool SPLIT, int HC, int CPW = 2>
 __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT) {
+    static_assert(CPW == 2 || (CPW == 4 && !SPLIT), "four chunks per wave: unsplit form only");
     using M = MfmaT<T>;
     using x8 = typename M::x8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -81,6 +88,9 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
 
     const int lane = lane_id(), wave = uniform((int)(threadIdx.x >> 6)), rho = lane & 15, q = lane >> 4;
     const int h = P.h;
+    auto xl_slot = [&](int k) -> float * {  // CPW = 4: [3 NW slots][4][h][4] f32x4 logits of the chunks beyond a wave's first, behind pg
+        return pg + ((P.S_sel + 3) & ~3) + ((size_t)((k - 1) * NW + wave) * 4 * h) * 16;
+    };
     int row = blockIdx.x, sp = 0;
     if constexpr (SPLIT) {  // the NS workgroups of a row sit on one XCD (workgroups go round-robin over the 8 XCDs)
         const int per = 8 * P.NS, grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
@@ -100,20 +110,21 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     for (int s = 0; s < 2; ++s) qf[s] = *(const x8 *)((const T *)P.Q + ((int64_t)row * h + hc) * 64 + 32 * s + 8 * q);
     const T *kb = (const T *)P.Kc + b * P.csb + (int64_t)g * P.csg;
     const int c_lo = SPLIT ? sp * P.cpg : 0, c_hi = SPLIT ? min(P.nchunk, c_lo + P.cpg) : P.nchunk;
-    constexpr int CPW = 2;
-    x8 a[CPW][4][2];
-    f32x4 acc[CPW][4];
+    constexpr int REGC = CPW == 2 ? 2 : 1;  // chunks of a wave whose logits stay in registers
+    x8 a[2][4][2];
+    f32x4 acc[REGC][4];
+    auto load_chunk = [&](int c, x8 (&dst)[4][2]) {
 #pragma unroll
-    for (int k = 0; k < CPW; ++k) {
-        const int c = c_lo + wave + NW * k;
-        if (c < c_hi) {
+        for (int u = 0; u < 4; ++u) {
+            const int r = min(c * 64 + 16 * u + rho, P.S_cmp - 1);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = min(c * 64 + 16 * u + rho, P.S_cmp - 1);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a[k][u][s] = *(const x8 *)(kb + (int64_t)r * P.css + 32 * s + 8 * q);
-            }
+            for (int s = 0; s < 2; ++s) dst[u][s] = *(const x8 *)(kb + (int64_t)r * P.css + 32 * s + 8 * q);
         }
+    };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = c_lo + wave + NW * k;
+        if (c < c_hi) load_chunk(c, a[k]);
     }
     // (behind the K_cmp loads in program order: vector memory operations complete in order, the scores must not wait for these)
     DecPrefetch pre{-1, nullptr};
@@ -129,48 +140,83 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     }
 
     for (int i = threadIdx.x; i < P.S_sel; i += NW * 64) pg[i] = 0.f;  // blocks without a compressed row keep a zero score
+    // scaled logits of chunk c (MFMA rows = 64 compressed rows, columns = heads) and the chunk's (max, sum exp2) per head: the arithmetic of
+    // decode_logits_mfma_kernel
+    auto chunk_logits = [&](int c, const x8 (&src)[4][2], f32x4 (&z)[4]) {
 #pragma unroll
-    for (int k = 0; k < CPW; ++k) {
-        const int c = c_lo + wave + NW * k;
-        if (c < c_hi) {
+        for (int u = 0; u < 4; ++u) {
+            f32x4 zz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < 2; ++s) zz = M::mma(src[u][s], qf[s], zz);
+            z[u] = zz;
+        }
+    };
+    auto chunk_stats = [&](int c, f32x4 (&z)[4]) {
+        float m = -INFINITY;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) z = M::mma(a[k][u][s], qf[s], z);
-                acc[k][u] = z;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = z[u][j] * P.c2;
+                z[u][j] = v;
+                if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) m = fmaxf(m, v);
             }
-            // scaled logits and the chunk's (max, sum exp2) per head: the arithmetic of decode_logits_mfma_kernel
-            float m = -INFINITY;
+        m = xor32_max(xor16_max(m));  // (= the xor-16, xor-32 shuffle steps of decode_logits_mfma_kernel: same bits)
+        float l = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc[k][u][j] * P.c2;
-                    acc[k][u][j] = v;
-                    if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) m = fmaxf(m, v);
+            for (int j = 0; j < 4; ++j)
+                if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(z[u][j] - m);
+        l = xor32_add(xor16_add(l));
+        if constexpr (SPLIT) {
+            if (rho < h) {  // write-through (sc1) stores: no release fence needed (cdna guide, Guideline 16 R1)
+                if (q == 0)
+                    __hip_atomic_store((unsigned long long *)(P.part_g + (((int64_t)row * h + rho) * DSTEP_CH + c) * 2),
+                                       ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q == 3)
+                    __hip_atomic_store((unsigned *)(P.halo_g + ((int64_t)row * DSTEP_CH + c) * 16 + rho), __float_as_uint(z[3][3]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (rho < h) {
+                if (q == 0) *(f32x2 *)(part + (rho * DSTEP_CH + c) * 2) = (f32x2){m, l};
+                if (q == 3) halo[c * 16 + rho] = z[3][3];  // row 64 c + 63: the half tap of the next chunk's first block
+            }
+        }
+    };
+    if constexpr (CPW == 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = c_lo + wave + NW * k;
+            if (c < c_hi) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) z = M::mma(a[k][u][s], qf[s], z);
+                    acc[k][u] = z;
                 }
-            m = xor32_max(xor16_max(m));  // (= the xor-16, xor-32 shuffle steps of decode_logits_mfma_kernel: same bits)
-            float l = 0.f;
+                chunk_stats(c, acc[k]);
+            }
+        }
+    } else {
+        // chunk 0 -> registers, chunks 1 .. 3 -> LDS; the loads of chunk k + 2 go out as soon as the MFMAs of chunk k have read its fragments
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int k = 0; k < CPW; ++k) {
+            const int c = wave + NW * k;
+            if (c < c_hi) {
+                f32x4 z[4];
+                chunk_logits(c, a[k & 1], z);
+                if (k + 2 < CPW && c + 2 * NW < c_hi) load_chunk(c + 2 * NW, a[k & 1]);
+                chunk_stats(c, z);
+                if (k == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) l += __builtin_amdgcn_exp2f(acc[k][u][j] - m);
-            l = xor32_add(xor16_add(l));
-            if constexpr (SPLIT) {
-                if (rho < h) {  // write-through (sc1) stores: no release fence needed (cdna guide, Guideline 16 R1)
-                    if (q == 0)
-                        __hip_atomic_store((unsigned long long *)(P.part_g + (((int64_t)row * h + rho) * DSTEP_CH + c) * 2),
-                                           ((unsigned long long)__float_as_uint(l) << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (q == 3)
-                        __hip_atomic_store((unsigned *)(P.halo_g + ((int64_t)row * DSTEP_CH + c) * 16 + rho), __float_as_uint(acc[k][3][3]), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                if (rho < h) {
-                    if (q == 0) *(f32x2 *)(part + (rho * DSTEP_CH + c) * 2) = (f32x2){m, l};
-                    if (q == 3) halo[c * 16 + rho] = acc[k][3][3];  // row 64 c + 63: the half tap of the next chunk's first block
+                    for (int u = 0; u < 4; ++u) acc[0][u] = z[u];
+                } else if (rho < h) {
+                    float *slot = xl_slot(k);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) *(f32x4 *)(slot + ((u * h + rho) * 4 + q) * 4) = z[u];
                 }
             }
         }
@@ -348,7 +394,17 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
         const int c = c_lo + wave + NW * k;
-        if (c < c_hi) blocks_of_chunk(c, acc[k], c > 0 ? halo[(c - 1) * 16 + hc] : 0.f);
+        if (c < c_hi) {
+            if (k < REGC) {
+                blocks_of_chunk(c, acc[k], c > 0 ? halo[(c - 1) * 16 + hc] : 0.f);
+            } else {
+                f32x4 z[4];  // lanes of columns >= h read the last head's values, as their accumulators would hold them (never used)
+                const float *slot = xl_slot(k);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) z[u] = *(const f32x4 *)(slot + ((u * h + hc) * 4 + q) * 4);
+                blocks_of_chunk(c, z, halo[(c - 1) * 16 + hc]);
+            }
+        }
     }
     if constexpr (SPLIT) {
         // second meeting, nobody waits: the scores of this workgroup's blocks are published (sc1, drained), one lane takes a ticket; the
@@ -406,6 +462,228 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
     DS_TS(10);
 }
 
+// ---- one-pass form (round 4): many rows at a long context ------------------------------------------------------------------------
+// B >= 128 sequences at 64k: a row's 64 chunks neither stay in the accumulators of one workgroup (2 per wave) nor can R teams of
+// workgroups be resident together, and one 16-wave workgroup per CU with the later logits in LDS (CPW = 4 above) leaves every CU's
+// chain -- log-sum-exp, scores, top-n: ~11 us of 50 per row, HBM idle -- exposed, all CUs in step (profiles/r04/decode_cold_notes.txt).
+// Here a row is ONE 8-wave workgroup again (two rows per CU: one row's chain under the other's sweep / gather) at up to 8 chunks per wave:
+// what a wave keeps of a chunk is not its 16 logits per lane but the Eq.9 sums of their exponentials RELATIVE TO THE CHUNK'S OWN MAXIMUM,
+//     E[h, j] = 1/2 e(4j-1) + e(4j) + e(4j+1) + e(4j+2) + 1/2 e(4j+3),   e(i) = exp2(x[h, i] - m_c[h])
+// -- 4 registers per chunk, and the exponentials are the ones the chunk's (max, sum) record needs anyway: ONE exponential per logit instead
+// of two.  With the row's log-sum-exp ml[h] the score of block j is  sum_h E[h, j] exp2(m_c[h] - ml[h])  (+ the half tap of the previous
+// chunk's last row for a chunk's first block, from the edge logits every form publishes).  Same (max, sum) records, same ml, same selector
+// and gather as the other forms; the scores carry one more rounding (<= 2 ulp against exp2(x - ml) summed directly), so the RANGES are those
+// of the exact forms wherever the 13th / 14th ranking keys are further apart than that -- the contract for scores computed from Q / K
+//  -- and exact-tie order is only guaranteed by the exact forms.  The plan picks this form only where they do not apply.
+template <typename T, int NW, int HC>
+__global__ __launch_bounds__(NW * 64, 4) void decode_step_onepass_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT) {
+    using M = MfmaT<T>;
+    using x8 = typename M::x8;
+    constexpr int CPW = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr bool PREF = NW == 16;
+    float *part = (float *)(lds + (PREF ? DEC_ATT_TILE : 0));
+    float *halo = part + DSTEP_PART;
+    float *pg = halo + DSTEP_HALO;  // [S_sel]
+    float *mlw = (float *)(lds + NW * DEC_ATT_TILE);
+    int *scr = (int *)(mlw + NW * 16);
+    int *list = scr + 128;
+    int *misc = list + 68;
+    [[maybe_unused]] unsigned char *ktiles = lds + NW * DEC_ATT_TILE + DSTEP_TAIL;
+
+    const int lane = lane_id(), wave = uniform((int)(threadIdx.x >> 6)), rho = lane & 15, q = lane >> 4;
+    const int h = P.h;
+    const int row = blockIdx.x;
+    [[maybe_unused]] const bool ts_on = row == P.R / 2;
+    DS_TS(0);
+    const int g = row % P.G;
+    const int64_t b = row / P.G;
+    const int hc = min(rho, h - 1);
+    x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *(const x8 *)((const T *)P.Q + ((int64_t)row * h + hc) * 64 + 32 * s + 8 * q);
+    const T *kb = (const T *)P.Kc + b * P.csb + (int64_t)g * P.csg;
+    const int nchunk = P.nchunk;
+    x8 a[2][4][2];
+    auto load_chunk = [&](int c, x8 (&dst)[4][2]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = min(c * 64 + 16 * u + rho, P.S_cmp - 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dst[u][s] = *(const x8 *)(kb + (int64_t)r * P.css + 32 * s + 8 * q);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (wave + NW * k < nchunk) load_chunk(wave + NW * k, a[k]);
+    DecPrefetch pre{-1, nullptr};
+    if constexpr (PREF) {
+        const int cb = P.t_token >> 6, t_end = min(P.t_token + 1, AT.S_kv);
+        const int slot = wave == 0 ? 0 : wave - 13;
+        if ((wave == 0 || wave >= 14) && cb >= 2 && cb < P.S_sel && AT.kss == 64) {
+            const int blk = wave == 0 ? 0 : cb - (15 - wave);
+            pre.tok0 = 64 * blk;
+            pre.ktile = ktiles + slot * DEC_ATT_TILE;
+            decode_prefetch_chunk<T>(AT, row, pre.tok0, min(64, t_end - pre.tok0), lds + wave * DEC_ATT_TILE, ktiles + slot * DEC_ATT_TILE);
+        }
+    }
+    for (int i = threadIdx.x; i < P.S_sel; i += NW * 64) pg[i] = 0.f;
+
+    // ---- phase 1: per chunk the (max, sum exp2) record, the edge logit, and the Eq.9 sums of the chunk's blocks relative to its maximum
+    float E[CPW][4];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = wave + NW * k;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) E[k][u] = 0.f;
+        if (c < nchunk) {
+            f32x4 z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) zz = M::mma(a[k & 1][u][s], qf[s], zz);
+                z[u] = zz;
+            }
+            if (k + 2 < CPW && c + 2 * NW < nchunk) load_chunk(c + 2 * NW, a[k & 1]);  // two chunks (16 KiB per wave) in flight throughout
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = z[u][j] * P.c2;
+                    z[u][j] = v;
+                    if (c * 64 + 16 * u + 4 * q + j < P.S_cmp) m = fmaxf(m, v);
+                }
+            m = xor32_max(xor16_max(m));
+            const float edge = z[3][3];
+            float l = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = (c * 64 + 16 * u + 4 * q + j < P.S_cmp) ? __builtin_amdgcn_exp2f(z[u][j] - m) : 0.f;
+                    z[u][j] = e;
+                    l += e;  // (a masked row adds +0: exact -- the sum has the bits of the other forms' record)
+                }
+            l = xor32_add(xor16_add(l));
+            if (rho < h) {
+                if (q == 0) *(f32x2 *)(part + (rho * DSTEP_CH + c) * 2) = (f32x2){m, l};
+                if (q == 3) halo[c * 16 + rho] = edge;
+            }
+            float rot_prev = 0.f;  // (the half tap of row 64 c - 1 belongs to another chunk's scale: added in phase 2b)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float rot = __shfl(z[u][3], (lane + 48) & 63, 64);
+                const float tapm1 = (q == 0) ? rot_prev : rot;
+                rot_prev = rot;
+                float slc = fmaf(0.5f, tapm1, z[u][0]);
+                slc += z[u][1];
+                slc += z[u][2];
+                E[k][u] = fmaf(0.5f, z[u][3], slc);
+            }
+        }
+    }
+    DS_TS(1);
+    lds_barrier();
+    DS_TS(4);
+    // ---- phase 2a: per-head log-sum-exp from the chunk records (the arithmetic of decode_step_kernel: same bits)
+    const int nr = (nchunk + 15) >> 4;
+    for (int h0 = 0; h0 < h; h0 += 4) {
+        const int hh = h0 + q;
+        float mv[8], lv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = rho + 16 * i;
+            mv[i] = -INFINITY;
+            lv[i] = 0.f;
+            if (i < nr && hh < h && idx < nchunk) {
+                const f32x2 r = *(const f32x2 *)(part + (hh * DSTEP_CH + idx) * 2);
+                mv[i] = r[0];
+                lv[i] = r[1];
+            }
+        }
+        float m = fmaxf(fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3])), fmaxf(fmaxf(mv[4], mv[5]), fmaxf(mv[6], mv[7])));
+        m = fmaxf(m, row_ror<8>(m));
+        m = fmaxf(m, row_ror<4>(m));
+        m = fmaxf(m, row_ror<2>(m));
+        m = fmaxf(m, row_ror<1>(m));
+        float av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = (i < nr && rho + 16 * i < nchunk) ? lv[i] * __builtin_amdgcn_exp2f(mv[i] - m) : 0.f;
+            if (i + 4 < nr && rho + 16 * (i + 4) < nchunk) av[i] += lv[i + 4] * __builtin_amdgcn_exp2f(mv[i + 4] - m);
+        }
+        float s = (av[0] + av[2]) + (av[1] + av[3]);
+        s += row_ror<8>(s);
+        s += row_ror<4>(s);
+        s += row_ror<2>(s);
+        s += row_ror<1>(s);
+        if (rho == 0 && hh < h) mlw[wave * 16 + hh] = m + __builtin_amdgcn_logf(s);
+    }
+    wave_lds_fence();
+    const float ml = mlw[wave * 16 + hc];
+    DS_TS(5);
+    // ---- phase 2b: scores of the wave's blocks: E scaled to the row's normaliser, the previous chunk's half tap, Eq.10 head sum (ascending h)
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        const int c = wave + NW * k;
+        if (c < nchunk) {
+            const float f = __builtin_amdgcn_exp2f(part[(hc * DSTEP_CH + c) * 2] - ml);
+            const float hp = c > 0 ? 0.5f * __builtin_amdgcn_exp2f(halo[(c - 1) * 16 + hc] - ml) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float slc = E[k][u] * f;
+                if (u == 0 && q == 0) slc += hp;
+                float grp;
+#define NSA_DS_HS(K) grp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x100 | K, 0xf, 0xf, true));
+                if constexpr (HC == 6) {
+                    const float src = slc;
+                    grp = slc;
+                    NSA_DS_HS(1) NSA_DS_HS(2) NSA_DS_HS(3) NSA_DS_HS(4) NSA_DS_HS(5)
+                } else {
+                    const float src = rho < h ? slc : 0.f;
+                    grp = src;
+                    NSA_DS_HS(1) NSA_DS_HS(2) NSA_DS_HS(3) NSA_DS_HS(4) NSA_DS_HS(5) NSA_DS_HS(6) NSA_DS_HS(7) NSA_DS_HS(8)
+                    NSA_DS_HS(9) NSA_DS_HS(10) NSA_DS_HS(11) NSA_DS_HS(12) NSA_DS_HS(13) NSA_DS_HS(14) NSA_DS_HS(15)
+                }
+#undef NSA_DS_HS
+                const int j = 16 * c + 4 * u + q;
+                if (rho == 0 && j < P.S_sel) pg[j] = grp;
+            }
+        }
+    }
+    DS_TS(6);
+    lds_barrier();
+    DS_TS(7);
+    // ---- phase 3 / 4: top-n + forced blocks (one wave), then the gather over the picked blocks -- decode_step_kernel's
+    int rs = 0, re = 0;
+    if (wave == 0) {
+        int nb = 0;
+        switch (cand) {
+            case 1: select_topn_row_regs<1>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 2: select_topn_row_regs<2>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 4: select_topn_row_regs<4>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 8: select_topn_row_regs<8>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            case 16: select_topn_row_regs<16>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+            default: select_topn_row_regs<32, true>(SP, pg, P.t_token, rs, re, scr, list, &nb); break;
+        }
+        if (lane == 0) misc[0] = nb;
+    }
+    DS_TS(8);
+    lds_barrier();
+    if (wave == 0 && lane < SP.W) {
+        int32_t *out = SP.out + (int64_t)row * SP.W * 2;
+        out[2 * lane] = rs;
+        out[2 * lane + 1] = re;
+    }
+    const int NC = uniform(misc[0]);
+    const ListChunks ch{list, min(P.t_token + 1, AT.S_kv)};
+    DS_TS(9);
+    decode_attend_chunks<T, NW>(AT, row, ch, NC, lds, qf, pre);
+    DS_TS(10);
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 // arrival tickets of the split form: owned by the library, one zeroed array per (device, stream) -- launches of one stream are ordered
 // and every launch leaves its tickets at zero, launches of different streams never share an array
@@ -421,7 +699,13 @@ static int *decode_tickets(hipStream_t st, int64_t rows) {
     const int64_t n = rows < 4096 ? 4096 : rows * 2;
     int *p = nullptr;
     if (hipMalloc(&p, sizeof(int) * n) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, sizeof(int) * n) != hipSuccess) return nullptr;  // (synchronous: once per stream; an outgrown array stays allocated -- a launch may still use it)
+    // zeroed ON THE LAUNCH STREAM: the fill is ordered before the first kernel that reads the tickets whatever kind of stream `st` is (a plain
+    // hipMemset runs on the null stream, which a non-blocking stream does not wait for).  Once per stream; an outgrown array stays
+    // allocated -- a launch may still use it
+    if (hipMemsetAsync(p, 0, sizeof(int) * n, st) != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
     tab[key] = {p, n};
     return p;
 }
@@ -444,14 +728,37 @@ static int device_cu_count() {
     return cus[dev];
 }
 
-// waves per row workgroup and workgroups per row (1 = the unsplit kernel); false = this shape is not for the one-launch step.
-// The workgroups of a split row meet inside the launch (one of them polls for the others): R * NS of them must be resident together.
-static bool decode_step_plan(int64_t R, int nchunk, int *nw_out, int *ns_out) {
+// bytes of score data the unsplit kernel keeps in the V-tile area, and what that area holds
+static size_t dstep_score_bytes(int nw, int h, int S_sel, int cpw) {
+    return sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)((S_sel + 3) & ~3)) + (cpw == 4 ? (size_t)3 * nw * 256 * h : 0);
+}
+static size_t dstep_score_room(int nw) { return (size_t)(nw == 16 ? 13 : nw) * DEC_ATT_TILE; }
+
+// waves per row workgroup, workgroups per row (1 = an unsplit kernel) and the kernel form; false = this shape is not for the one-launch step.
+// form 0: logits in the accumulators (two chunks per wave; a long row as a team of NS workgroups that meet inside the launch: R * NS of them
+// must be resident together); 1: one 16- or 8-wave workgroup per row with four chunks per wave, the later chunks' logits in LDS (exact: the
+// bits of form 0); 2: the one-pass form, eight chunks per wave (decode_step_onepass_kernel: scores within 2 ulp of the exact forms).
+// TUNE_DECODE_WIDE: -1 = forms 1 / 2 only where a team would not fit the chip (1 while the row fits it, else 2), 0 = never, 1 / 2 = that
+// form wherever the row fits it.
+static bool decode_step_plan(int64_t R, int nchunk, int h, int S_sel, int *nw_out, int *ns_out, int *form_out) {
     const int nw = dec_att_waves(R);
     const int64_t slots = (int64_t)device_cu_count() * (nw == 16 ? 1 : 2);  // 1024-thread workgroups hold a CU each (LDS), 512-thread ones share it
-    const int mode = tuning(TUNE_DECODE_SPLIT);
+    const int mode = tuning(TUNE_DECODE_SPLIT), wide = tuning(TUNE_DECODE_WIDE);
     int ns = (nchunk + 2 * nw - 1) / (2 * nw);  // at most two chunks per wave (the accumulators of a wave's chunks stay in registers)
-    if (ns > 1 && R * ns > slots) return false;
+    const bool wide_fits = nchunk > 2 * nw && nchunk <= 4 * nw && dstep_score_bytes(nw, h, S_sel, 4) <= dstep_score_room(nw);
+    const bool onepass_fits = nchunk <= 8 * nw && dstep_score_bytes(nw, h, S_sel, 2) <= dstep_score_room(nw);
+    const bool no_team = ns > 1 && R * ns > slots;
+    *nw_out = nw;
+    *ns_out = 1;
+    if (wide_fits && (wide == 1 || (wide < 0 && no_team && nw == 16))) {
+        *form_out = 1;
+        return true;
+    }
+    if (onepass_fits && (wide == 2 || (wide < 0 && no_team))) {
+        *form_out = 2;
+        return true;
+    }
+    if (no_team) return false;
     if (mode > 0) {
         int want = mode < ns ? ns : (mode > nchunk ? nchunk : mode);
         while (want > ns && R * want > slots) --want;
@@ -466,8 +773,8 @@ static bool decode_step_plan(int64_t R, int nchunk, int *nw_out, int *ns_out) {
         const int t8 = nchunk / 8;  // workgroups of 8 chunks
         if (nchunk >= 32 && t8 > ns && R * t8 <= slots) ns = t8;
     }
-    *nw_out = nw;
     *ns_out = ns;
+    *form_out = 0;
     return true;
 }
 
@@ -475,8 +782,8 @@ bool decode_step_supported(int64_t R, int dtype, int h, int Dk, int Dv, int S_cm
                            int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss,
                            const void *Q, const void *Kc, const void *K, const void *V) {
     if (tuning(TUNE_DECODE_STEP) == 0 || tuning(TUNE_DECODE_UNFUSED) > 0) return false;
-    int nw, ns;
-    if (R < 1 || S_cmp < 1 || !decode_step_plan(R, (S_cmp + 63) / 64, &nw, &ns)) return false;
+    int nw, ns, form;
+    if (R < 1 || S_cmp < 1 || S_sel < 1 || h < 1 || h > 16 || !decode_step_plan(R, (S_cmp + 63) / 64, h, S_sel, &nw, &ns, &form)) return false;
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16 && d > 0 && l == 2 * d && l_sel == 4 * d &&
            l_sel == 64 && S_cmp >= 1 && S_cmp <= 64 * DSTEP_CH && S_sel >= 1 && S_sel <= 2048 && n_top >= 3 && n_top <= 64 && t_token >= 0 &&
            S_kv >= t_token + 1 && (int64_t)S_kv * 128 < ((int64_t)1 << 31) && kcs % 8 == 0 && kcb % 8 == 0 && kcg % 8 == 0 &&
@@ -489,8 +796,9 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     const int64_t R = (int64_t)B * G;
     NSA_CHECK_ARG(R >= 1 && R <= (1 << 24), "decode step: bad row count");
     const int nchunk = ((S_cmp + 63) / 64);
-    int nw = 16, ns = 1;
-    NSA_CHECK_ARG(decode_step_plan(R, nchunk, &nw, &ns), "decode step: shape not covered (decode_step_supported)");
+    int nw = 16, ns = 1, form = 0;
+    NSA_CHECK_ARG(decode_step_plan(R, nchunk, h, S_sel, &nw, &ns, &form), "decode step: shape not covered (decode_step_supported)");
+    const int cpw = form == 1 ? 4 : 2;
     DecStepParams P{Q, Kc, nullptr, nullptr, nullptr, nullptr, (int)R, G, h, S_cmp, S_sel, ns, nchunk, (nchunk + ns - 1) / ns, t_token, 0, kcb, kcg, kcs, scale * LOG2E};
     P.spin = tuning(TUNE_DECODE_TEAM_SPIN) >= 0 ? tuning(TUNE_DECODE_TEAM_SPIN) : 512;  // polls of ~0.5-1 us each before a workgroup goes on alone
     if (ns > 1) {
@@ -514,15 +822,21 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     void (*k)(DecStepParams, SelectParams, int, DecAttnArgs);
     const bool bf = dtype == NSA_DT_BF16, split = ns > 1;
 #define NSA_DSK(NW_, SP_, HC_) (bf ? decode_step_kernel<__bf16, NW_, SP_, HC_> : decode_step_kernel<_Float16, NW_, SP_, HC_>)
-    if (h == 6) k = nw == 16 ? (split ? NSA_DSK(16, true, 6) : NSA_DSK(16, false, 6)) : (split ? NSA_DSK(8, true, 6) : NSA_DSK(8, false, 6));
+#define NSA_DSK4(NW_, HC_) (bf ? decode_step_kernel<__bf16, NW_, false, HC_, 4> : decode_step_kernel<_Float16, NW_, false, HC_, 4>)
+#define NSA_DSK1(NW_, HC_) (bf ? decode_step_onepass_kernel<__bf16, NW_, HC_> : decode_step_onepass_kernel<_Float16, NW_, HC_>)
+    if (form == 2) k = h == 6 ? (nw == 16 ? NSA_DSK1(16, 6) : NSA_DSK1(8, 6)) : (nw == 16 ? NSA_DSK1(16, 0) : NSA_DSK1(8, 0));
+    else if (cpw == 4) k = h == 6 ? (nw == 16 ? NSA_DSK4(16, 6) : NSA_DSK4(8, 6)) : (nw == 16 ? NSA_DSK4(16, 0) : NSA_DSK4(8, 0));
+    else if (h == 6) k = nw == 16 ? (split ? NSA_DSK(16, true, 6) : NSA_DSK(16, false, 6)) : (split ? NSA_DSK(8, true, 6) : NSA_DSK(8, false, 6));
     else k = nw == 16 ? (split ? NSA_DSK(16, true, 0) : NSA_DSK(16, false, 0)) : (split ? NSA_DSK(8, true, 0) : NSA_DSK(8, false, 0));
+#undef NSA_DSK1
+#undef NSA_DSK4
 #undef NSA_DSK
     const size_t lds = dstep_lds(nw);
     // the score data sits in V tiles 1 .. (the prefetching waves of the 16-wave form own tiles 0, 14, 15)
-    NSA_CHECK_ARG(sizeof(float) * (DSTEP_PART + DSTEP_HALO + (size_t)S_sel) <= (size_t)(nw == 16 ? 13 : nw) * DEC_ATT_TILE, "decode step: S_sel too large");
+    NSA_CHECK_ARG(dstep_score_bytes(nw, h, S_sel, cpw) <= dstep_score_room(nw), "decode step: S_sel too large");
     {  // raise the dynamic-LDS limit once per kernel (the runtime call costs about a millisecond)
         static std::mutex mu;
-        static void *raised[16] = {};
+        static void *raised[32] = {};
         std::lock_guard<std::mutex> lk(mu);
         bool done = false;
         for (void *r : raised) done |= (r == (void *)k);

@@ -704,10 +704,13 @@ def test_scorer_64bit_output_offsets(nv, orc):
     assert norm(rs) == norm(want)
 
 
-@pytest.mark.parametrize("S_ctx,B", [(64, 2), (700, 3), (1041, 2), (4096, 5), (16384, 3), (40000, 2), (65536, 2), (65600, 2), (100001, 1), (131072, 2)])
+@pytest.mark.parametrize("S_ctx,B", [(64, 2), (700, 3), (1041, 2), (4096, 5), (16384, 3), (20000, 3), (32768, 2), (40000, 2), (65536, 2), (65600, 2), (100001, 1),
+                                     (131072, 2)])
 def test_decode_step_kernel_forms_agree(nv, orc, tune, S_ctx, B):
     """the one-launch decode step (sel_decode_fused.hip) in every form -- 16 / 8 waves per row, the logits phase of a row on one
-    workgroup or split over 2 / 4 / 16 (the last arriver finishes the row) -- against the three separate launches (DECODE_UNFUSED = 1)
+    workgroup or split over 2 / 4 / 16 (the last arriver finishes the row), or (round 4, DECODE_WIDE = 1) a long row in ONE workgroup with
+    four chunks per wave and the later chunks' logits in LDS (20000 / 32768 on 8 waves, 40000 / 65536 on 16; elsewhere the switch changes
+    nothing) -- against the three separate launches (DECODE_UNFUSED = 1)
     and the round-2 kernels (DECODE_STEP = 0): ranges bit-identical everywhere, O bit-identical wherever the gather uses the same
     number of waves (the partial records of a row are merged in wave order); and the ranges against the oracle's selector on the
     device scores, O against the oracle's attention.  Reference path: nsa/core/nsa_attention.py:651-672, 704-830."""
@@ -731,6 +734,10 @@ def test_decode_step_kernel_forms_agree(nv, orc, tune, S_ctx, B):
             outs[(nw, f"step, split {ns}")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
             outs[(nw, f"step, split {ns}, again")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)  # tickets left clean, run-to-run bits
         tune("DECODE_SPLIT", -1)
+        tune("DECODE_WIDE", 1)
+        outs[(nw, "step, wide")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        outs[(nw, "step, wide, again")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        tune("DECODE_WIDE", -1)
         tune("DECODE_STEP", 0)
         outs[(nw, "round-2 kernels")] = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
     torch.cuda.synchronize()
@@ -745,6 +752,48 @@ def test_decode_step_kernel_forms_agree(nv, orc, tune, S_ctx, B):
     f = lambda a: a.float().cpu().numpy()  # noqa: E731
     O_or = orc.sel_attention_masked(f(Q), f(K), f(V), r_ref.cpu().numpy()[:, None])
     assert np.abs(f(O_ref) - O_or).max() <= 1e-2
+
+
+@pytest.mark.parametrize("S_ctx,B,h", [(700, 3, 6), (4096, 5, 6), (16384, 4, 6), (40000, 3, 6), (65536, 4, 6), (65536, 2, 4), (100001, 2, 6), (131072, 2, 3)])
+def test_decode_step_one_pass_form(nv, orc, tune, S_ctx, B, h):
+    """the one-pass form of the decode step (DECODE_WIDE = 2; what the plan picks for B >= 128 at 64k, where neither the accumulators of one
+    workgroup nor co-resident teams hold a row): per chunk the Eq.9 sums of exponentials relative to the chunk's own maximum, scaled to the row's
+    log-sum-exp afterwards -- one exponential per logit, one more rounding per score (<= 2 ulp).  The contract for ranges computed from Q / K
+    (DESIGN.md 2): every row whose 13th / 14th ranking keys are further apart than the score noise must give the ranges of the exact forms bit
+    for bit (here: relative gap > 1e-5 against <= 2.4e-7 of noise; random rows all pass the gate), and with equal ranges O is bit-identical
+    (same gather).  Reference path: nsa/core/nsa_attention.py:651-672, selection_scorer.py:42-61, 89-116, 124-249."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S_ctx * 3 + B + h)
+    G, D, n = 2, 64, 16
+    meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g).bfloat16()  # noqa: E731
+    Q, Kc, K, V = mk(B, 1, G, h, D), mk(B, G, meta.S_cmp, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)
+    t = S_ctx - 1
+    p = nv.selection_scores(Q, Kc, meta)[:, 0]  # exact scores [B,G,S_sel]
+    cur = t // 64
+    cand = p.clone()
+    cand[..., 0] = -1
+    cand[..., max(cur - 1, 0):] = -1  # forced blocks and the blocks a selector cannot read leave the ranking
+    top = cand.topk(min(n - 3 + 1, cand.shape[-1]), dim=-1).values
+    k_rest = n - 3
+    gated = torch.ones(B, G, dtype=torch.bool, device="cuda")
+    if top.shape[-1] > k_rest:
+        a, b_ = top[..., k_rest - 1], top[..., k_rest]
+        gated = (b_ < 0) | ((a - b_) > 1e-5 * a.abs())
+    n_checked = 0
+    for nw in (16, 8):
+        tune("DECODE_WAVES", nw)
+        tune("DECODE_WIDE", -1), tune("DECODE_UNFUSED", 1)
+        O0, r0 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        tune("DECODE_UNFUSED", -1), tune("DECODE_WIDE", 2)
+        O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        O2, r2 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+        torch.cuda.synchronize()
+        assert torch.equal(r1, r2) and torch.equal(O1, O2)  # run to run
+        assert torch.equal(r0[gated], r1[gated]), nw
+        assert torch.equal(O0[:, 0][gated], O1[:, 0][gated]), nw
+        n_checked += int(gated.sum())
+    assert n_checked >= B * G  # the gate must not be vacuous (random rows: gaps of 1e-2 .. 1e-4 relative)
 
 
 @pytest.mark.parametrize("h", [1, 3, 4, 8, 16])
@@ -767,6 +816,16 @@ def test_decode_step_kernel_other_group_sizes(nv, tune, h, dtype):
         O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
         torch.cuda.synchronize()
         assert torch.equal(r0, r1) and torch.equal(O0, O1), (h, ns)
+    if h <= 6:  # the four-chunks-per-wave form (logits of the later chunks in LDS, 256 h bytes per chunk) with the generic head sum
+        S_ctx = 40000
+        meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+        Q, Kc, K, V = mk(B, 1, G, h, D), mk(B, G, meta.S_cmp, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)
+        tune("DECODE_SPLIT", -1), tune("DECODE_UNFUSED", 1)
+        O0, r0 = nv.selection_decode_step(Q, Kc, K, V, meta, n, S_ctx - 1)
+        tune("DECODE_UNFUSED", -1), tune("DECODE_WIDE", 1)
+        O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, S_ctx - 1)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1) and torch.equal(O0, O1), (h, "wide")
 
 
 @pytest.mark.parametrize("S_ctx", [3000, 16384, 65536])

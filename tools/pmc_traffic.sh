@@ -2,7 +2,7 @@
 # HBM traffic of a workload by PMC counters (run on the GPU box):  tools/pmc_traffic.sh <tag> <kernel-name-filter> <prof_hot.py args...>
 # FETCH_SIZE and WRITE_SIZE in SEPARATE passes with --kernel-trace only (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2 of 4), then
 # tools/traffic_summary.py applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 of a wide streaming read)
-# and writes profiles/<round>/traffic_<tag>.json (per launch; round = $NSA_PROFILE_ROUND, default r03).
+# and writes profiles/<round>/traffic_<tag>.json (per launch; round = $NSA_PROFILE_ROUND, default r04).
 set -e
 TAG=$1; FILT=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_$TAG

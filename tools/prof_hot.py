@@ -2,7 +2,8 @@
 """Focused workloads for rocprofv3 passes (kernel trace or PMC): the hot path of bench.py at one shape, a few launches.
 
     ... -- python3 tools/prof_hot.py prefill <S> <B> <iters> [attn|scores|select|all]     (select + attend launch / scorer / both)
-    ... -- python3 tools/prof_hot.py decode  <B> <S_ctx> <iters>                   (nsa_sel_decode_step)
+    ... -- python3 tools/prof_hot.py decode  <B> <S_ctx> <iters>                   (nsa_sel_decode_step, the same cache every step: warm)
+    ... -- python3 tools/prof_hot.py decode_cold <B> <S_ctx> <iters>               (the steps rotate over bench.py's independent cache sets: cold)
 """
 import os
 import sys
@@ -29,6 +30,16 @@ if mode == "prefill":
             nv.select_and_attend(p, Q, K, V, meta, bench.N_SEL, mode="batched")
         if stage == "select":
             nv.select_topn_ranges_batched(p, meta, bench.N_SEL, S)
+    torch.cuda.synchronize()
+elif mode == "decode_cold":
+    B, S, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    n_sets = min(32, -(-bench.COLD_BYTES_BETWEEN_USES // bench.decode_step_bytes(B, S)) + 1)
+    meta, sets = bench.decode_cache_sets(nv, B, S, dev, n_sets)
+    O = torch.empty(B, 1, bench.G, bench.H, bench.D, device=dev, dtype=torch.bfloat16)
+    rg = torch.empty(B, bench.G, bench.N_SEL, 2, device=dev, dtype=torch.int32)
+    for i in range(iters + n_sets):
+        q1, Kc, K, V = sets[i % n_sets]
+        nv.selection_decode_step(q1, Kc, K, V, meta, bench.N_SEL, S - 1, out=O, ranges_out=rg)
     torch.cuda.synchronize()
 else:
     B, S, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

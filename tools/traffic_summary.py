@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh) -> profiles/<round>/traffic_<tag>.json (round: $NSA_PROFILE_ROUND, default r03), per launch of the kernels whose name contains
+"""FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh) -> profiles/<round>/traffic_<tag>.json (round: $NSA_PROFILE_ROUND, default r04), per launch of the kernels whose name contains
 the filter (comma separated alternatives; every matching kernel of one step is summed, the per-kernel figures are kept too)."""
 import csv
 import glob
@@ -36,7 +36,7 @@ rec = {"workload": tag, "command": "tools/prof_hot.py " + what, "kernels": kerne
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                "(gfx950 counts the 128-B requests of 16-B/lane streaming reads at 64 B); mean per launch; traffic_bytes = sum over the "
                "kernels of one step"}
-rnd = os.environ.get("NSA_PROFILE_ROUND", "r03")
+rnd = os.environ.get("NSA_PROFILE_ROUND", "r04")
 path = os.path.join(root, "profiles", rnd, f"traffic_{tag}.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(rec, open(path, "w"), indent=1)
