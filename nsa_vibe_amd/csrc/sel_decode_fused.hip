@@ -738,8 +738,9 @@ static size_t dstep_score_room(int nw) { return (size_t)(nw == 16 ? 13 : nw) * D
 // form 0: logits in the accumulators (two chunks per wave; a long row as a team of NS workgroups that meet inside the launch: R * NS of them
 // must be resident together); 1: one 16- or 8-wave workgroup per row with four chunks per wave, the later chunks' logits in LDS (exact: the
 // bits of form 0); 2: the one-pass form, eight chunks per wave (decode_step_onepass_kernel: scores within 2 ulp of the exact forms).
-// TUNE_DECODE_WIDE: -1 = forms 1 / 2 only where a team would not fit the chip (1 while the row fits it, else 2), 0 = never, 1 / 2 = that
-// form wherever the row fits it.
+// TUNE_DECODE_WIDE: -1 = form 2 where a team would not fit the chip (measured cold, profiles/r04/decode_cold_forms.txt: B=256@64k 75.5 us
+// against 98.4 for form 1 and 98.1 for the round-2 two-launch route; B=128@64k 47.4 / 52.3 / 56.8), 0 = never, 1 / 2 = that form wherever
+// the row fits it.
 static bool decode_step_plan(int64_t R, int nchunk, int h, int S_sel, int *nw_out, int *ns_out, int *form_out) {
     const int nw = dec_att_waves(R);
     const int64_t slots = (int64_t)device_cu_count() * (nw == 16 ? 1 : 2);  // 1024-thread workgroups hold a CU each (LDS), 512-thread ones share it
@@ -750,7 +751,7 @@ static bool decode_step_plan(int64_t R, int nchunk, int h, int S_sel, int *nw_ou
     const bool no_team = ns > 1 && R * ns > slots;
     *nw_out = nw;
     *ns_out = 1;
-    if (wide_fits && (wide == 1 || (wide < 0 && no_team && nw == 16))) {
+    if (wide_fits && wide == 1) {
         *form_out = 1;
         return true;
     }
