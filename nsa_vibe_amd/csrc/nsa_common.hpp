@@ -54,7 +54,7 @@ enum Tune {
     TUNE_DECODE_STEP,       // NSA_HIP_DECODE_STEP: 1 = the one-launch decode step of sel_decode_fused.hip wherever it applies (default), 0 = the round-2 kernels
     TUNE_DECODE_TEAM_SPIN,  // NSA_HIP_DECODE_TEAM_SPIN: split decode step, polls a workgroup waits for its team before it goes on alone; -1 = 512, 0 = never waits
     TUNE_DECODE_WIDE,       // NSA_HIP_DECODE_WIDE: one-launch decode step, a long row in ONE workgroup: 1 = four chunks per wave with the later chunks' logits in LDS (exact), 2 = the one-pass form (eight chunks per wave, scores within 2 ulp), wherever the row fits; -1 = only where a team of workgroups would not fit the chip; 0 = never
-    TUNE_SEL_KSPLIT_T1,     // NSA_HIP_SEL_KSPLIT_T1 / _T2: key-split attention, rows from this position on (position = row + S_kv - S) are split 2-way / 4-way; -1 = 16384 / 32768
+    TUNE_SEL_KSPLIT_T1,     // NSA_HIP_SEL_KSPLIT_T1 / _T2: key-split attention, rows from this position on (position = row + S_kv - S) are split 2-way / 4-way; -1 = 32768 / never
     TUNE_SEL_KSPLIT_T2,
     TUNE_COUNT
 };

@@ -47,12 +47,18 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 // 2 rows (12 of 16 columns) per tile and four tiles.  MFMA and VALU issue do not overlap on a gfx950 SIMD (tools/ubench/issue_rates.hip), so
 // the idle quarter of every tile cost both its MFMAs and its softmax arithmetic.  Rows 2 and 5 straddle two tiles: every column keeps its own
 // running max / sum / output (a column is one (row, head) pair either way), only the ownership masks see the difference.
-// KSPLIT: two workgroups per row group, each walking one half of the 8-block (128 KiB) stripes of the keys, on different XCDs (the pair index
-// carries the half, pairs go round-robin over the XCDs).  At 64k a (b,g)'s K/V is 16 MiB against 4 MiB of L2 per XCD and the launch is bound by
-// L2-miss traffic: half the footprint per XCD cuts the misses by more than the partial records cost (profiles/r02/p_key_split.txt).  Each half
-// leaves (m, l, s) in fp32 and its normalised O / s in f16 (2^-11 relative: below the rounding of the output dtype; s = 1 unless the half's output
-// leaves the f16 range, then a power of two) per (row, head); a second small
-// launch merges the two in fixed order.
+// KSPLIT (round 2; by row position since round 4): at 64k a (b,g)'s K/V is 16 MiB against 4 MiB of L2 per XCD and the plain walk is bound by
+// L2-miss traffic.  A row at position t touches keys [0, t] only, so the keys are split by where the row sits: rows below T1 are walked whole
+// and write O directly, rows in [T1, T2) by TWO workgroups -- the even / odd 8-block (128 KiB) stripes of the keys -- and rows from T2 on by
+// FOUR (stripe index mod 4).  All eight XCDs work on the same walk (pair, zone, class) at the same time, every XCD on every eighth workgroup of
+// it: balanced for any number of pairs, each XCD keeps its own copy of the walk's key region.  A split row leaves per class (m, l, s) in fp32
+// and its normalised O / s in f16 (2^-11 relative: below the rounding of the output dtype; s = 1 unless the class's output leaves the f16
+// range, then a power of two) per (row, head); a second small launch merges the 2 / 4 records of a row in class order (bitwise reproducible).
+// Defaults T1 = 32k, T2 = off, measured (profiles/r04/key_split_zones.txt): the L2 hit rate follows the region size as the gather
+// microbenchmark says (0.71 unsplit -> 0.88 two classes above 16k -> 0.94 four classes above 32k, memory-side reads 13.1 -> 5.5 -> 2.3 GB at
+// 64k x 4), but the launch does not: from two classes on it is bound by the CU's L2 -> LDS path with ONE 16 KiB block in flight per wave
+// (8 x 16 KiB / ~1.1 us), and every further class costs its set-up and its records -- four classes above 32k are 5 % SLOWER than two, rows
+// below 32k are best left whole.  (Round 2 split every row two ways, each (pair, half) on its own XCD: 15.8 ms at 64k x 16, now 15.5.)
 template <typename T, int NT, bool RS, bool FLAT, bool KSPLIT = false>
 __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnParams P, SelectParams SP, int cand) {
     static_assert(!FLAT || NT == 3, "the flat layout is 3 tiles of 16 columns = 8 rows x 6 heads");
@@ -70,18 +76,40 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     const int nbg = (int)(P.R / P.S);
     const int W4 = (ngrp + 3) >> 2;  // workgroups per (b,g)
     int bg, tc;
-    if (P.map_mode == 2) {  // whole (b,g) pairs per XCD (workgroups go round-robin over the 8 XCDs)
+    // KSPLIT: zone of the workgroup's rows (0 unsplit, 1 two key classes, 2 four) and its class, from blockIdx alone (decoded again in the
+    // epilogue: nothing of it stays live across the block loop, whose scalar registers are all taken).  Workgroups go round-robin over the
+    // 8 XCDs: XCD x takes every eighth workgroup of each walk, walks in the order (pair; zone 0, zone 1 class 0, 1, zone 2 class 0 .. 3), so
+    // the chip gathers from one <= 4 MiB key region at a time
+    auto ks_decode = [&](int &bg_, int &tc_, int &zone, int &cls) -> bool {
+        int bid = blockIdx.x;
+        asm volatile("" : "+s"(bid));  // (opaque: the compiler must not keep the first decode's results alive for the later ones)
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int per = P.ks_wa + 2 * P.ks_wb + 4 * P.ks_wc;
+        bg_ = idx / per;
+        int rem = idx - bg_ * per, i, w0, w1;
+        zone = 0, cls = 0;
+        if (rem < P.ks_wa) {
+            i = rem, w0 = 0, w1 = P.ks_w1;
+        } else if (rem < P.ks_wa + 2 * P.ks_wb) {
+            rem -= P.ks_wa;
+            zone = 1, cls = rem / P.ks_wb, i = rem - cls * P.ks_wb, w0 = P.ks_w1, w1 = P.ks_w2;
+        } else {
+            rem -= P.ks_wa + 2 * P.ks_wb;
+            zone = 2, cls = rem / P.ks_wc, i = rem - cls * P.ks_wc, w0 = P.ks_w2, w1 = 0x7fffffff;
+        }
+        tc_ = w0 + 8 * i + xcd;
+        return tc_ < w1;
+    };
+    if constexpr (KSPLIT) {
+        int zone, cls;
+        if (!ks_decode(bg, tc, zone, cls) || tc >= W4) return;
+    } else if (P.map_mode == 2) {  // whole (b,g) pairs per XCD (workgroups go round-robin over the 8 XCDs)
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bg = (idx / W4) * 8 + xcd;
         tc = idx % W4;
     } else {
         bg = blockIdx.x / W4;
         tc = blockIdx.x % W4;
-    }
-    [[maybe_unused]] int ksp = 0;  // KSPLIT: the walk of this workgroup covers the even (0) / odd (1) key stripes; bg counts (pair, half)
-    if constexpr (KSPLIT) {
-        ksp = bg & 1;
-        bg >>= 1;
     }
     const int grp = 4 * tc + wave;
     if (grp >= ngrp || bg >= nbg) return;
@@ -184,7 +212,12 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     unsigned u0 = 0u;
     for (int r = 0; r < ntok; ++r)
         if (lane < NW) u0 |= touchw[r * NW + lane];
-    if constexpr (KSPLIT) u0 &= ksp ? 0xFF00FF00u : 0x00FF00FFu;  // stripes of 8 blocks, alternating: both halves see the same causal shape
+    if constexpr (KSPLIT) {  // stripes of 8 blocks, dealt to the classes in turn: every class sees the same causal shape
+        int bg_, tc_, zone, cls;
+        ks_decode(bg_, tc_, zone, cls);
+        if (zone == 1) u0 &= 0x00FF00FFu << (8 * cls);
+        else if (zone == 2) u0 &= 0x000000FFu << (8 * cls);
+    }
     unsigned long long nz0 = __ballot(u0 != 0u);
 
     const unsigned char *Kb = (const unsigned char *)((const T *)P.K + (int64_t)b * P.ksb + (int64_t)g * P.ksg);
@@ -414,6 +447,11 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     }
 
     // ---- epilogue
+    [[maybe_unused]] int kzone = 0, ksp = 0;
+    if constexpr (KSPLIT) {
+        int bg_, tc_;
+        ks_decode(bg_, tc_, kzone, ksp);
+    }
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) {
         float ltot = lrun[nn];
@@ -424,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
         if (!rowbit(nn)) continue;
         const int64_t orow = (((int64_t)b * P.S + tw0 + col_row(nn)) * P.G + g) * h + col_head(nn);
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-        if constexpr (KSPLIT) {  // partial record of this half: ml[orow][half] = (m, l, s, -), po[orow][half][64] = O / (l s) in f16
+        if (KSPLIT && kzone > 0) {  // partial record of this class: ml[rec] = (m, l, s, -), po[rec][64] = O / (l s) in f16
             // s = 1 unless the half's output leaves the f16 range (bf16 inputs with |V| > 32768): then the power of two that brings its
             // largest element back below 2^15 -- the merge multiplies it back in, so the record never overflows where the plain walk is finite
             float amax = 0.f;
@@ -440,9 +478,14 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
                 sc = __uint_as_float((unsigned)(e + 127) << 23);
                 isc = __uint_as_float((unsigned)(127 - e) << 23);
             }
+            // records: zone 1 rows first ([bg][t - r1][head][2]), then zone 2 ([bg][t - r2][head][4]); the (m, l, s) quadruples, then the f16 rows
+            const int nbg_ = (int)(P.R / P.S), t = tw0 + col_row(nn), hd = col_head(nn);
+            const int64_t n1 = (int64_t)nbg_ * (P.ks_r2 - P.ks_r1) * h * 2, nrec = n1 + (int64_t)nbg_ * (P.S - P.ks_r2) * h * 4;
+            const int64_t rec = kzone == 1 ? (((int64_t)bg * (P.ks_r2 - P.ks_r1) + (t - P.ks_r1)) * h + hd) * 2 + ksp
+                                           : n1 + (((int64_t)bg * (P.S - P.ks_r2) + (t - P.ks_r2)) * h + hd) * 4 + ksp;
             float *ml = (float *)P.part;
-            _Float16 *po = (_Float16 *)(ml + (int64_t)P.R * h * 8) + (orow * 2 + ksp) * 64;
-            if (q == 0) *(f32x4 *)(ml + (orow * 2 + ksp) * 4) = (f32x4){mrun[nn], ltot, sc, 0.f};
+            _Float16 *po = (_Float16 *)(ml + nrec * 4) + rec * 64;
+            if (q == 0) *(f32x4 *)(ml + rec * 4) = (f32x4){mrun[nn], ltot, sc, 0.f};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f16x4 ov;
@@ -464,45 +507,90 @@ __global__ __launch_bounds__(256, 2) void sel_attn_blocks_mfma_kernel(SelAttnPar
     }
 }
 
-// merge of the two key halves: thread = (row * h + head, 8 output elements)
+// merge of the 2 / 4 class records of a split row, in class order: thread = ((pair, row >= r1, head), 8 output elements)
 template <typename T>
 __global__ __launch_bounds__(256) void sel_attn_ksplit_combine_kernel(const float *__restrict__ ml, const _Float16 *__restrict__ po, T *__restrict__ O,
-                                                                      float *__restrict__ lse, int64_t nrh) {
+                                                                      float *__restrict__ lse, int nbg, int S, int G, int h, int r1, int r2) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int oct = threadIdx.x & 7;
-    if (i >= nrh) return;
-    const f32x4 r0 = *(const f32x4 *)(ml + i * 8), r1 = *(const f32x4 *)(ml + i * 8 + 4);  // (m, l, s, -) of either half
-    const float M = fmaxf(r0[0], r1[0]);
-    const float w0 = r0[1] > 0.f ? r0[1] * __builtin_amdgcn_exp2f(r0[0] - M) : 0.f, w1 = r1[1] > 0.f ? r1[1] * __builtin_amdgcn_exp2f(r1[0] - M) : 0.f;
-    const float L = w0 + w1;
-    // (s = 1 in every ordinary record: x * 1.0f is exact, the result is that of the unscaled merge bit for bit)
-    const float a0 = L > 0.f ? (w0 / L) * r0[2] : 0.f, a1 = L > 0.f ? (w1 / L) * r1[2] : 0.f;
-    const f16x8 p0 = *(const f16x8 *)(po + (i * 2) * 64 + 8 * oct), p1 = *(const f16x8 *)(po + (i * 2 + 1) * 64 + 8 * oct);
+    const int64_t per = (int64_t)(S - r1) * h;
+    if (i >= per * nbg) return;
+    const int bg = (int)(i / per);
+    const int rem = (int)(i - bg * per), t = r1 + rem / h, hd = rem % h;
+    const int64_t n1 = (int64_t)nbg * (r2 - r1) * h * 2;
+    const int k = t < r2 ? 2 : 4;
+    const int64_t rec = t < r2 ? (((int64_t)bg * (r2 - r1) + (t - r1)) * h + hd) * 2 : n1 + (((int64_t)bg * (S - r2) + (t - r2)) * h + hd) * 4;
+    f32x4 r[4];
+    float M = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        r[c] = c < k ? *(const f32x4 *)(ml + (rec + c) * 4) : (f32x4){-INFINITY, 0.f, 1.f, 0.f};  // (m, l, s, -) of every class
+        M = fmaxf(M, r[c][0]);
+    }
+    float w[4], L = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        w[c] = r[c][1] > 0.f ? r[c][1] * __builtin_amdgcn_exp2f(r[c][0] - M) : 0.f;
+        if (c < k) L += w[c];
+    }
     typedef typename MfmaT<T>::x8 x8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < k) {
+            // (s = 1 in every ordinary record: x * 1.0f is exact, the result is that of the unscaled merge bit for bit)
+            const float a = L > 0.f ? (w[c] / L) * r[c][2] : 0.f;
+            const f16x8 p = *(const f16x8 *)(po + (rec + c) * 64 + 8 * oct);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = c == 0 ? (float)p[j] * a : acc[j] + (float)p[j] * a;
+        }
+    }
     x8 out;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[j] = Elt<T>::from_f((float)p0[j] * a0 + (float)p1[j] * a1);
-    *(x8 *)(O + i * 64 + 8 * oct) = out;
-    if (lse && oct == 0) lse[i] = L > 0.f ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
+    for (int j = 0; j < 8; ++j) out[j] = Elt<T>::from_f(acc[j]);
+    const int b = bg / G, g = bg - b * G;
+    const int64_t orow = (((int64_t)b * S + t) * G + g) * h + hd;
+    *(x8 *)(O + orow * 64 + 8 * oct) = out;
+    if (lse && oct == 0) lse[orow] = L > 0.f ? (M + __builtin_amdgcn_logf(L)) * LN2 : -INFINITY;
 }
 
 // ---- host side ----------------------------------------------------------------------------
-// key-split form wanted for this shape?  TUNE_SEL_KSPLIT: -1 = when the launch is bound by L2-miss traffic (measured, merge launch included,
-// profiles/r02/p_key_split.txt: 0.78-0.83 x the time of the plain walk at 64k with B = 4 ... 16, 0.90-0.93 x with B = 1 ... 3, 0.94 x at 48k
-// with B = 4; 1.03 x at 40k, 1.09 x at 48k with B = 1, 1.12 x at 32k), 0 never, 1 always
+// key-split form wanted for this shape?  TUNE_SEL_KSPLIT: -1 = by the K/V footprint of a (b,g) pair against the 4 MiB of L2 per XCD, 0 never,
+// 1 always.  The zones of the form (rows walked whole / in two / in four key classes) follow the rows' positions, so a short context is all
+// zone 0 and costs nothing but the different workgroup order; the rule below is where the measured gain starts (profiles/r04/key_split_zones.txt).
 static bool ksplit_rule(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R) {
     const int mode = tuning(TUNE_SEL_KSPLIT);
     if (mode == 0 || S <= 0 || Dv != 64 || Dk != 64 || !(dtype == NSA_DT_BF16 || dtype == NSA_DT_F16)) return false;
-    const int64_t nbg = R / S;
     if (mode > 0) return true;
-    // keyed on the K/V footprint of a (b,g) pair against the 4 MiB of L2 per XCD (>= 16 MiB, or >= 12 MiB with at least 8 pairs), not on the
-    // number of range slots: a caller with a few wide ranges sees the same cache behaviour as the selector's 16 blocks
-    (void)n;
-    return S_kv >= 65536 || (S_kv >= 49152 && nbg >= 8);
+    (void)n, (void)R;
+    return S_kv >= 32768;  // (at 32k no row is split yet: the shared-walk workgroup order alone is 0.96 x the plain order; 0.89 x at 48k, 0.80-0.82 x at 64k)
+}
+// zone boundaries in rows of a (b,g), multiples of the rows of one workgroup: rows whose position (row + S_kv - S: the rows are the last S
+// positions of the context) is below T1 are walked whole, below T2 in two key classes, the others in four
+static void ksplit_zones(int h, int S, int S_kv, int *r1, int *r2) {
+    const int rpw = 4 * 4 * (16 / h);  // rows per workgroup of the NT = 4 form
+    const int t1 = tuning(TUNE_SEL_KSPLIT_T1) >= 0 ? tuning(TUNE_SEL_KSPLIT_T1) : 32768;
+    const int t2 = tuning(TUNE_SEL_KSPLIT_T2) >= 0 ? tuning(TUNE_SEL_KSPLIT_T2) : (1 << 30);
+    const int off = S_kv > S ? S_kv - S : 0;
+    auto rows_below = [&](int t) {
+        int64_t r = (int64_t)t - off;
+        r = r < 0 ? 0 : (r > S ? S : r);
+        r = (r + rpw - 1) / rpw * rpw;
+        return (int)(r > S ? (S + rpw - 1) / rpw * rpw : r);
+    };
+    *r1 = rows_below(t1);
+    *r2 = rows_below(t2 > t1 ? t2 : t1);
 }
 size_t sel_attn_ksplit_workspace(int dtype, int h, int Dk, int Dv, int S, int S_kv, int n, int64_t R) {
-    if (!ksplit_rule(dtype, h, Dk, Dv, S, S_kv, n, R)) return 0;
-    return (size_t)R * h * (8 * sizeof(float) + 2 * 64 * sizeof(_Float16));
+    if (!ksplit_rule(dtype, h, Dk, Dv, S, S_kv, n, R) || h < 1 || h > 16) return 0;
+    int r1, r2;
+    ksplit_zones(h, S, S_kv, &r1, &r2);
+    const int64_t nbg = R / S;
+    const int64_t rows2 = r2 > S ? 0 : S - r2, rows1 = (r2 > S ? S : r2) - (r1 > S ? S : r1);
+    const size_t nrec = (size_t)nbg * h * (2 * (size_t)(rows1 > 0 ? rows1 : 0) + 4 * (size_t)rows2);
+    return nrec * (4 * sizeof(float) + 64 * sizeof(_Float16)) + 16;  // (16: a launch without any split row still gets a non-null workspace)
 }
 
 // Column tiles per wave for a shape, 0 = not covered (the query-tile kernel takes it).  TUNE_SEL_BLOCKS: -1 auto, 0 off, N forces NT = N.
@@ -538,10 +626,25 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
     P.wave_lds = 2 * blk::TILE_BYTES + 4 * (rg_ints + bm_ints);
     const size_t lds = 4 * (size_t)P.wave_lds;
     NSA_CHECK_ARG(lds <= 160 * 1024, "sel_attn_blocks: %zu B of LDS needed", lds);
-    const int64_t nbg = (P.R / P.S) * (KSPLIT ? 2 : 1);  // KSPLIT: (pair, key half) takes the place of the pair in the workgroup order
+    const int64_t nbg = P.R / P.S;
     const int64_t ngrp = (P.S + tpw - 1) / tpw;
     const int64_t W4 = (ngrp + 3) / 4;
-    NSA_CHECK_ARG(nbg * W4 < (int64_t)1 << 31, "sel_attn_blocks: grid too large");
+    int64_t grid = nbg * W4;
+    if constexpr (KSPLIT) {
+        int r1, r2;
+        ksplit_zones(P.h, P.S, P.S_kv, &r1, &r2);
+        const int rpw = 4 * tpw;
+        const int64_t wA = r1 / rpw < W4 ? r1 / rpw : W4, wB = r2 / rpw < W4 ? r2 / rpw : W4;
+        P.ks_w1 = (int)wA;
+        P.ks_w2 = (int)wB;
+        P.ks_r1 = (int)(wA * rpw < P.S ? wA * rpw : P.S);
+        P.ks_r2 = (int)(wB * rpw < P.S ? wB * rpw : P.S);
+        P.ks_wa = (int)((wA + 7) / 8);
+        P.ks_wb = (int)((wB - wA + 7) / 8);
+        P.ks_wc = (int)((W4 - wB + 7) / 8);
+        grid = 8 * nbg * ((int64_t)P.ks_wa + 2 * P.ks_wb + 4 * P.ks_wc);
+    }
+    NSA_CHECK_ARG(grid < (int64_t)1 << 31, "sel_attn_blocks: grid too large");
     P.map_mode = (nbg % 8 == 0) ? 2 : 1;
     SelectParams SP{};
     int cand = 0;
@@ -555,14 +658,17 @@ static int launch_blocks_t(const SelAttnParams &P0, hipStream_t st) {
     void (*k)(SelAttnParams, SelectParams, int) = tuning(TUNE_SEL_ROWSUM) ? sel_attn_blocks_mfma_kernel<T, NT, true, FLAT, KSPLIT>
                                                                           : sel_attn_blocks_mfma_kernel<T, NT, false, FLAT, KSPLIT>;
     if (lds > 64 * 1024) NSA_HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)(nbg * W4)), dim3(256), lds, st, P, SP, cand);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, P, SP, cand);
     NSA_LAUNCH_CHECK("sel_attn_blocks_mfma");
     if constexpr (KSPLIT) {
-        const int64_t nrh = P.R * P.h;
-        const float *ml = (const float *)P.part;
-        hipLaunchKernelGGL(sel_attn_ksplit_combine_kernel<T>, dim3((unsigned)((nrh * 8 + 255) / 256)), dim3(256), 0, st, ml,
-                           (const _Float16 *)(ml + nrh * 8), (T *)P.O, P.lse, nrh);
-        NSA_LAUNCH_CHECK("sel_attn_ksplit_combine");
+        const int64_t items = nbg * (int64_t)(P.S - P.ks_r1) * P.h;  // (row, head) pairs with records
+        if (items > 0) {
+            const int64_t nrec = nbg * P.h * (2 * (int64_t)(P.ks_r2 - P.ks_r1) + 4 * (int64_t)(P.S - P.ks_r2));
+            const float *ml = (const float *)P.part;
+            hipLaunchKernelGGL(sel_attn_ksplit_combine_kernel<T>, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, ml,
+                               (const _Float16 *)(ml + nrec * 4), (T *)P.O, P.lse, (int)nbg, P.S, P.G, P.h, P.ks_r1, P.ks_r2);
+            NSA_LAUNCH_CHECK("sel_attn_ksplit_combine");
+        }
     }
     return NSA_OK;
 }
@@ -576,7 +682,7 @@ int launch_sel_attn_blocks_mfma(const SelAttnParams &P, int dtype, int nt, hipSt
     const bool flat = nt == 4 && P.h == 6 && (fmode > 0 || (fmode < 0 && (int64_t)P.S_kv <= (int64_t)384 * P.n));
     // key halves on different XCDs (see the kernel): needs the caller's workspace, no fused selector, and the walk of a row group long enough
     const size_t ks_need = (nt == 4 && !flat && !P.fuse_select) ? sel_attn_ksplit_workspace(dtype, P.h, P.Dk, P.Dv, P.S, P.S_kv, P.n, P.R) : 0;
-    if (ks_need > 0 && P.ks_ws && P.ks_bytes >= ks_need && (int64_t)P.R * P.h * 8 < ((int64_t)1 << 31))
+    if (ks_need > 0 && P.ks_ws && P.ks_bytes >= ks_need)
         return dtype == NSA_DT_BF16 ? launch_blocks_t<__bf16, 4, false, true>(P, st) : launch_blocks_t<_Float16, 4, false, true>(P, st);
     if (dtype == NSA_DT_BF16) {
         if (flat) return launch_blocks_t<__bf16, 3, true>(P, st);

@@ -26,6 +26,9 @@ struct SelAttnParams {
     int tpw, nw, wave_lds;  // query-tile form (sel_attn_rows_mfma.hip): rows per wave, 32-tile bitmap words per row, LDS bytes per wave
     void *ks_ws;            // key-split form of the block kernel (sel_attn_blocks_mfma.hip): caller's workspace (16-byte aligned) or null
     size_t ks_bytes;
+    // key-split form, filled by its launcher: rows [0, ks_r1) of a (b,g) are walked unsplit, [ks_r1, ks_r2) in two key classes, [ks_r2, S) in
+    // four (multiples of the 32 rows of a workgroup); workgroups per XCD of one class of each zone
+    int ks_r1, ks_r2, ks_w1, ks_w2, ks_wa, ks_wb, ks_wc;  // (ks_w1 / ks_w2: first workgroup of zones 1 / 2; ks_r = min(ks_w * rows per workgroup, S))
 };
 
 struct SelAttnBwdParams {

@@ -706,11 +706,23 @@ def test_flat_block_kernel_matches_four_tile_form(nv, orc, tune, S):
     assert np.abs(out[1][0].float().cpu().numpy() - want).max() <= 1e-2
 
 
-@pytest.mark.parametrize("B,S,G", [(2, 4096, 2), (1, 1501, 2), (3, 700, 1), (1, 300, 4)])
+# zone thresholds of the key-split form (SEL_KSPLIT_T1 / _T2 as fractions of S): every row in four classes; every row in two; the mixed form
+# (rows whole / in two / in four by position, what a 64k context gets); whole + four only; and the defaults (16k / 32k: a short context is
+# walked whole through the split launcher)
+KS_ZONES = [(0.0, 0.0), (0.0, 1e9), (0.25, 0.5), (0.4, 0.4), (None, None)]
+
+
+def _ks_tune(tune, S, z):
+    for name, f in (("SEL_KSPLIT_T1", z[0]), ("SEL_KSPLIT_T2", z[1])):
+        tune(name, -1 if f is None else int(min(f * S, 2 ** 30)))
+
+
+@pytest.mark.parametrize("B,S,G", [(2, 4096, 2), (1, 1501, 2), (3, 700, 1), (1, 300, 4), (9, 1024, 2)])
 def test_key_split_block_kernel_matches_plain_walk(nv, orc, tune, B, S, G):
-    """the block form with the keys of a pair split over two workgroup sets (even / odd 8-block stripes, partial (m, l, O / l) records in f16,
-    merged by a second launch) against the plain walk and the oracle, output and log-sum-exp; forced on by the tuning switch (by itself it
-    only applies to long contexts)"""
+    """the block form with the keys of a row split over 2 / 4 workgroup sets by the row's position (8-block stripes dealt to the classes in
+    turn, partial (m, l, O / l) records in f16, merged by a second launch in class order; rows below the first threshold are walked whole and
+    written directly) against the plain walk and the oracle, output and log-sum-exp, for every zone layout; forced on by the tuning switch
+    (by itself it only applies to long contexts).  Semantics: nsa/core/attention_kernels.py:705-772."""
     torch.manual_seed(S + B)
     h, D = 6, 64
     meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
@@ -719,21 +731,51 @@ def test_key_split_block_kernel_matches_plain_walk(nv, orc, tune, B, S, G):
     V = torch.randn(B, G, S, D, device="cuda").bfloat16()
     rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, 16, S)
     rg[:, 5] = 0  # a row without any key
+    rg[:, S - 7] = 0  # (one in the last zone too)
     tune("SEL_FLAT", 0)
-    out = {}
-    for ks in (0, 1):
-        tune("SEL_KSPLIT", ks)
-        out[ks] = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
-    torch.cuda.synchronize()
-    assert (out[0][0].float() - out[1][0].float()).abs().max().item() <= 1.6e-2  # one bf16 ulp at |O| < 4
-    fin = torch.isfinite(out[0][1])
-    assert torch.equal(fin, torch.isfinite(out[1][1])) and (out[0][1][fin] - out[1][1][fin]).abs().max().item() <= 1e-3
-    assert not out[1][0][:, 5].any()
+    tune("SEL_KSPLIT", 0)
+    plain = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
     want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
-    assert np.abs(out[1][0].float().cpu().numpy() - want).max() <= 1e-2
-    # run to run: bit-identical (the halves are merged in a fixed order)
-    again = nv.selection_attention_hip(Q, K, V, rg)
-    assert torch.equal(again, out[1][0])
+    tune("SEL_KSPLIT", 1)
+    for z in KS_ZONES:
+        _ks_tune(tune, S, z)
+        out = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
+        torch.cuda.synchronize()
+        assert (plain[0].float() - out[0].float()).abs().max().item() <= 1.6e-2, z  # one bf16 ulp at |O| < 4
+        fin = torch.isfinite(plain[1])
+        assert torch.equal(fin, torch.isfinite(out[1])) and (plain[1][fin] - out[1][fin]).abs().max().item() <= 1e-3, z
+        assert not out[0][:, 5].any() and not out[0][:, S - 7].any(), z
+        assert np.abs(out[0].float().cpu().numpy() - want).max() <= 1e-2, z
+        if z == (None, None):  # every row below the first threshold: the plain walk's arithmetic, only the workgroup order differs
+            assert torch.equal(out[0], plain[0])
+        # run to run: bit-identical (the classes are merged in a fixed order)
+        again = nv.selection_attention_hip(Q, K, V, rg)
+        assert torch.equal(again, out[0]), z
+
+
+def test_key_split_rows_at_the_end_of_a_longer_context(nv, orc, tune):
+    """the zones follow the rows' POSITIONS (row + S_kv - S): a chunk of 512 query rows at the end of a 3000-key cache, thresholds at 2600 /
+    2800 positions, so the chunk holds rows of all three zones although its row indices start at 0"""
+    torch.manual_seed(11)
+    B, S, S_kv, G, h, D = 2, 512, 3000, 2, 6, 64
+    Q = torch.randn(B, S, G, h, D, device="cuda").bfloat16()
+    K = torch.randn(B, G, S_kv, D, device="cuda").bfloat16()
+    V = torch.randn(B, G, S_kv, D, device="cuda").bfloat16()
+    blk = torch.rand(B, S, G, (S_kv - S) // 64, device="cuda").topk(12, dim=-1).indices.sort(dim=-1).values.int()
+    rg = torch.zeros(B, S, G, 16, 2, dtype=torch.int32, device="cuda")
+    rg[..., :12, 0] = blk * 64
+    rg[..., :12, 1] = blk * 64 + 64
+    pos = (S_kv - S + torch.arange(S, device="cuda", dtype=torch.int32))[None, :, None]
+    rg[..., 12, 0] = (pos // 64) * 64  # the row's own partial block
+    rg[..., 12, 1] = pos + 1
+    tune("SEL_FLAT", 0), tune("SEL_KSPLIT", 0)
+    plain = nv.selection_attention_hip(Q, K, V, rg)
+    tune("SEL_KSPLIT", 1), tune("SEL_KSPLIT_T1", 2600), tune("SEL_KSPLIT_T2", 2800)
+    out = nv.selection_attention_hip(Q, K, V, rg)
+    torch.cuda.synchronize()
+    assert (plain.float() - out.float()).abs().max().item() <= 1.6e-2
+    want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
+    assert np.abs(out.float().cpu().numpy() - want).max() <= 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -750,19 +792,21 @@ def test_key_split_other_head_counts_and_f16(nv, orc, tune, dtype, h):
     V = torch.randn(B, G, S, D, device="cuda").to(dtype)
     rg = nv.select_topn_ranges_batched(torch.rand(B, S, G, meta.S_sel, device="cuda"), meta, 16, S)
     tune("SEL_FLAT", 0)
-    out = {}
-    for ks in (0, 1):
-        tune("SEL_KSPLIT", ks)
-        out[ks] = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
-    torch.cuda.synchronize()
     want, want_lse = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy(),
                                               return_lse=True)
-    for ks in (0, 1):
-        assert np.abs(out[ks][0].float().cpu().numpy() - want).max() <= TOL[dtype], (ks, h, dtype)
     fin = np.isfinite(want_lse)
-    assert np.array_equal(np.isfinite(out[1][1].cpu().numpy()), fin) and np.abs(out[1][1].cpu().numpy()[fin] - want_lse[fin]).max() <= 2e-2
     ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
-    assert (out[0][0].float() - out[1][0].float()).abs().max().item() <= 4 * ulp * 1.01  # a rounding step of the output at |O| < 4
+    tune("SEL_KSPLIT", 0)
+    plain = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
+    assert np.abs(plain[0].float().cpu().numpy() - want).max() <= TOL[dtype], (h, dtype)
+    tune("SEL_KSPLIT", 1)
+    for z in KS_ZONES[:4]:  # (rows per workgroup are 64 / 32 / 80 for h = 4 / 8 / 3: the zone boundaries round to them)
+        _ks_tune(tune, S, z)
+        out = nv.selection_attention_hip(Q, K, V, rg, return_lse=True)
+        torch.cuda.synchronize()
+        assert np.abs(out[0].float().cpu().numpy() - want).max() <= TOL[dtype], (z, h, dtype)
+        assert np.array_equal(np.isfinite(out[1].cpu().numpy()), fin) and np.abs(out[1].cpu().numpy()[fin] - want_lse[fin]).max() <= 2e-2, (z, h)
+        assert (plain[0].float() - out[0].float()).abs().max().item() <= 4 * ulp * 1.01, (z, h)  # a rounding step of the output at |O| < 4
 
 
 def test_key_split_records_survive_values_beyond_the_f16_range(nv, orc, tune):
@@ -778,7 +822,7 @@ def test_key_split_records_survive_values_beyond_the_f16_range(nv, orc, tune):
     tune("SEL_FLAT", 0)
     out = {}
     for ks in (0, 1):
-        tune("SEL_KSPLIT", ks)
+        tune("SEL_KSPLIT", ks), tune("SEL_KSPLIT_T1", 300), tune("SEL_KSPLIT_T2", 700)  # rows whole / in two / in four classes
         out[ks] = nv.selection_attention_hip(Q, K, V, rg).float()
     torch.cuda.synchronize()
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()

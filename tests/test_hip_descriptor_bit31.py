@@ -96,6 +96,7 @@ def test_prefill_forms_on_bit31_addresses(nv, arena, tune):
     Qb, Kb, Vb = c.take(Q), c.take(K), c.take(V)
     forms = [("SEL_BLOCKS", 4, "SEL_FLAT", 0), ("SEL_BLOCKS", 4, "SEL_FLAT", 1), ("SEL_BLOCKS", 4, "SEL_KSPLIT", 1),
              ("SEL_BLOCKS", 0, "SEL_ROWS", 1), ("SEL_BLOCKS", 0, "SEL_ROWS", 0), ("SEL_BLOCKS", 0, "SEL_ROWS", 3)]
+    tune("SEL_KSPLIT_T1", 400), tune("SEL_KSPLIT_T2", 900)  # the key-split form with rows in all three zones
     for a, av, b_, bv in forms:
         tune("SEL_FLAT", 0), tune("SEL_KSPLIT", 0), tune("SEL_ROWS", -1)
         tune(a, av), tune(b_, bv)
