@@ -292,8 +292,11 @@ NSA_API int nsa_pcmp_all(const void *Q, const void *K_cmp, float *p_cmp, int B, 
  *   32/16/64) and bf16/f16 inputs with Dk in {64,128}, h <= 16, a single MFMA kernel evaluates Eq.9 in
  *   closed form; every other case runs the query-chunked generic path and needs the workspace.
  *   causal_skip != 0: entries p_grp[b,t,g,j] of blocks the selector can never pick at t
- *   ((j+1) l' > t+1, masked to -inf by both selectors) are returned as 0 instead of being computed; causal_skip == 2 leaves them
- *   UNWRITTEN (saves the zero fill of p_grp -- 512 MiB at S = 64k; for callers that hand p_grp straight to the selectors).
+ *   ((j+1) l' > t+1, masked to -inf by both selectors) need not be computed: such an entry is returned as 0 -- or, on the MFMA route, as
+ *   its full computed value where the workgroup of the query (64 / 32 consecutive queries share a sweep that stops at the LAST block any
+ *   of them can read) computed the block for a later query of the group.  causal_skip == 2 additionally leaves the entries no query of the
+ *   workgroup can read UNWRITTEN (saves the zero fill of p_grp -- 512 MiB at S = 64k).  Either way only entries with (j+1) l' <= t+1 are
+ *   defined values of the reference: a caller that sums or ranks p_grp itself must apply that mask (both selectors here do).
  *   Few query rows (B*S*G <= 1024: decode) run a decode-shaped pair of kernels that spreads the K_cmp sweep of a
  *   row over many workgroups (any dtype / geometry); it needs B*S*G*h*S_cmp floats of workspace.
  *   variant: 0 auto, 1 generic, 2 MFMA (prefill), 3 decode-shaped.

@@ -398,14 +398,16 @@ class NSAAttention(nn.Module):
             self._fallback_counters["selection_hip_fails"] += 1
             self._fallback_counters["total_fallbacks"] += 1
             self._last_error = str(e)
-            if self._strict or not one_call:
-                raise  # ... the per-stage composition is the last executor there is: no CPU / eager-SDPA route exists by design
+            if self._strict or not one_call or "HIP error" in str(e):
+                # ... the per-stage composition is the last executor there is: no CPU / eager-SDPA route exists by design; and a HIP
+                # runtime / device error (a launch failure, a fault) is not a status return to route around: raised as it is
+                raise
             # ... and falls back to its next executor and returns normally: the layer composed from the separate native calls
             warnings.warn(f"nsa_vibe_amd: the one-call native layer failed ({e}); falling back to the per-stage native route", RuntimeWarning)
             try:
                 return self._prefill(x, kv, one_call=False) if prefill else self._decode(x, kv, one_call=False)
-            except Exception:
-                raise e
+            except Exception as e2:
+                raise e2 from e  # (both tracebacks: the per-stage route's failure, caused by the one-call route's)
 
     def _prefill(self, x: torch.Tensor, kv: NSA_KV, one_call: bool = True):
         B, S, _ = x.shape

@@ -138,3 +138,45 @@ def g19_rows():
     pre = np.unique(np.concatenate([np.arange(0, 200, 7), np.arange(200, G19_S_PRE - 96, 29), np.arange(G19_S_PRE - 96, G19_S_PRE)]))
     dec = np.unique(np.concatenate([np.arange(0, 100, 9), np.arange(100, G19_N_DEC - 40, 37), np.arange(G19_N_DEC - 40, G19_N_DEC)]))
     return pre.astype(np.int64), dec.astype(np.int64)
+
+
+# g20: the reference NSAAttention module at BASELINE configs[0]'s exact shape = the CLI defaults of bench/bench_decode.py:63-72 (dim 256, 8 heads,
+# G 2 -> h 4, d_k = d_v 32, l 32, d 16, l' 64, n 16, w 512), context 512 + 32 decode steps (oracle/make_m7c_module_goldens.py, second case).
+# Weights / inputs by the g19 recipe (bf16-representable PCG64 streams, regenerated on both sides).
+G20_CFG = dict(dim=256, n_heads=8, n_kv_groups=2, d_k=32, d_v=32, l=32, d=16, l_sel=64, n_sel=16, w=512)
+G20_S_PRE, G20_N_DEC, G20_B = 512, 512 + 32, 1
+
+
+def g20_state(names_shapes):
+    out = {}
+    for i, (name, shape) in enumerate(names_shapes):
+        shape = tuple(int(x) for x in shape)
+        r = _rng(20, i)
+        w = randn(r, *shape) / np.float32(np.sqrt(shape[1])) if len(shape) == 2 else randn(r, *shape) * np.float32(0.02)
+        out[name] = _bf16_round(w)
+    return out
+
+
+def g20_inputs():
+    r = _rng(20, 1000)
+    x_pre = _bf16_round(randn(r, G20_B, G20_S_PRE, G20_CFG["dim"]))
+    x_dec = _bf16_round(randn(r, G20_N_DEC, G20_B, 1, G20_CFG["dim"]))
+    return x_pre, x_dec
+
+
+def topn_gap(p_row, t, n_top=16, l_sel=64):
+    """gap between the last picked and the first rejected ranking key of one score row at token t (fp32 keys p - idx * 1e-8 as
+    nsa/core/selection_scorer.py:182-184 forms them; candidates = complete blocks minus the forced ones 0, t // l', t // l' - 1);
+    inf when nothing is rejected"""
+    S_sel = p_row.shape[-1]
+    nvalid = min(S_sel, (t + 1) // l_sel)
+    key = (np.asarray(p_row, np.float32) - np.arange(S_sel, dtype=np.float32) * np.float32(1e-8)).astype(np.float32)
+    ok = np.zeros(S_sel, bool)
+    ok[:nvalid] = True
+    cb = t // l_sel
+    for f in (0, cb, max(cb - 1, 0)):
+        if f < S_sel:
+            ok[f] = False
+    k = np.sort(key[ok])[::-1]
+    kk = n_top - 3
+    return float(k[kk - 1] - k[kk]) if kk >= 1 and k.size > kk else float("inf")

@@ -659,6 +659,7 @@ def test_native_call_failure_is_counted_and_falls_back(monkeypatch):
     from nsa_vibe_amd.nsa_attention import NSAAttention
 
     torch.manual_seed(0)
+    monkeypatch.setenv("NSA_HIP_STRICT", "0")  # (the suite runs strict by default, conftest.py: this test is about the non-strict contract)
     m = NSAAttention(256, 8, 2, 32, 32, l=32, d=16, l_sel=64, n_sel=8, w=128).cuda().bfloat16().eval()
     x = torch.randn(1, 200, 256, device="cuda", dtype=torch.bfloat16)
     real = _lib.lib()
@@ -792,16 +793,47 @@ def _row_err(got, ref):
     return err, float(np.abs(ref).max())
 
 
+def _live(r):
+    """the set of live ranges of one row (zero padding and the reference's inverted garbage slots dropped)"""
+    return frozenset((int(s), int(e)) for s, e in np.asarray(r).reshape(-1, 2) if e > s)
+
+
+# the bf16 layer's group scores differ from the fp32 reference's by the roundings of Q (after RoPE) and K_cmp (after pooling): measured on this
+# fixture the largest 13th / 14th key gap of a (row, group) pair whose selection flipped is 4.5e-5 (prefill, 3.5 % of the pairs flip) / 1.9e-5
+# (decode, 0.5 %); pairs decided by more than G19_GATE (78 % of the prefill pairs, 94 % of the decode ones) must select what the reference
+# selected
+G19_GATE = 1e-4
+
+
+def _g19_check(tag, err, scale, got_ranges, ref_ranges, gaps, min_gated):
+    """the gate of VERDICT r3 item 4: (a) EVERY (row, group) whose ranges are the reference's is within the north-star bf16 tolerance
+    (1e-2 x the output range: the layer output mixes both groups, so a row counts when both its groups agree); (b) every (row, group) whose
+    13th / 14th ranking keys are further apart than the bf16 score noise has the reference's ranges; the ungated fraction is printed"""
+    R, G = gaps.shape
+    same = np.array([[_live(got_ranges[r, g]) == _live(ref_ranges[r, g]) for g in range(G)] for r in range(R)])
+    gated = gaps > G19_GATE
+    tol = 1e-2 * max(scale, 1.0)
+    row_same = same.all(axis=1)
+    print(f"g19 {tag}: rows {R}, |ref| max {scale:.3f}; (row, group) pairs decided by more than {G19_GATE:g}: {gated.mean():.3f}; pairs with the reference's "
+          f"ranges: {same.mean():.4f} (gated: {same[gated].mean():.4f}); largest gap of a flipped pair: {gaps[~same].max() if (~same).any() else 0:.2e}; "
+          f"rows with both groups equal: {row_same.mean():.3f}, their max err {err[row_same].max():.2e} (tol {tol:.1e}); "
+          f"median err over all rows {np.median(err):.2e}")
+    assert gated.mean() >= min_gated, "the gate must hold most of the fixture"
+    assert same[gated].all(), f"a decided row selected other blocks than the reference: gaps {gaps[gated & ~same]}"
+    assert row_same.mean() >= 0.6
+    assert (err[row_same] <= tol).all(), float(err[row_same].max())
+
+
 @pytest.mark.parametrize("selector", ["sequential", "batched"])
 def test_m7c_geometry_prefill_matches_reference_module(selector):
     """nsa_layer_prefill (bf16: fused projections -> RoPE/append -> MFMA scorer -> top-n -> block-form MFMA selection attention -> gate ->
     output projection) against the REFERENCE NSAAttention module (CPU fp32, NSA_FORCE_SEL_MASK=1, gate forced onto the selected branch as
     nsa/tests/test_equiv_full_coverage.py:72; reference path nsa/core/nsa_attention.py:978-1448 batched, 1521-1723 sequential) at
     dim 768 / 12 heads / G 2 / d_k = d_v = 64 / l 32 / d 16 / l' 64 / n 16, S = 4096.  Weights and inputs are bf16-representable, so
-    the two sides differ by the bf16 roundings inside the layer (Q/K/V and O are bf16 tensors here, fp32 there) -- and, on a few rows,
-    by a selection flipped on a near tie of the bf16 scores (at S = 4096 the 13th and 14th of ~60 candidate scores are often closer than
-    the bf16 rounding of Q and K_cmp moves them: first GPU run 7 % of the batched rows, 2 % of the sequential ones).  Bars: the typical
-    row within the north-star bf16 tolerance scaled to the output range (measured median 1.1e-3); at most 10 % of the rows beyond 4x that."""
+    the two sides differ by the bf16 roundings inside the layer (Q/K/V and O are bf16 tensors here, fp32 there) -- and, on some rows,
+    by a selection flipped on a near tie of the bf16 scores.  Round 4: the fixture holds the reference's ranges and its 13th / 14th key gap
+    per sampled row, so the bar is a GATE, not a percentile (see _g19_check): every row with the reference's selection within 1e-2 of the
+    output range, every decided row with the reference's selection."""
     import golden_inputs as gi
 
     g, m = _g19_module(selector, torch.bfloat16)
@@ -812,37 +844,75 @@ def test_m7c_geometry_prefill_matches_reference_module(selector):
         out, kv = m(x, m.new_kv(x.shape[0], x.shape[1], "cuda", torch.bfloat16), prefill=True)
     torch.cuda.synchronize()
     rows = g["rows_pre"]
-    err, scale = _row_err(out.float().cpu().numpy()[:, rows], g[f"out_pre_{tag}"])
-    tol = 1e-2 * max(scale, 1.0)
-    print(f"g19 prefill {selector}: rows {err.size}, |ref| max {scale:.3f}, row err median {np.median(err):.2e} p90 {np.percentile(err, 90):.2e} "
-          f"max {err.max():.2e}; rows beyond {tol:.1e}: {(err > tol).mean():.4f}, beyond 4x: {(err > 4 * tol).mean():.4f}")
     assert torch.isfinite(out.float()).all()
-    assert np.median(err) <= tol and np.percentile(err, 75) <= tol and (err > 4 * tol).mean() <= 0.10
+    err, scale = _row_err(out.float().cpu().numpy()[0, rows], g[f"out_pre_{tag}"][0])
+    got_r = m._last_ranges[0, torch.from_numpy(rows).cuda()].cpu().numpy()
+    _g19_check(f"prefill {selector}", err, scale, got_r, g[f"ranges_pre_{tag}"], g[f"gap_pre_{tag}"], 0.5)
     assert m.get_fallback_counters()["total_fallbacks"] == 0
 
 
 def test_m7c_geometry_decode_matches_reference_module():
     """nsa_layer_decode_step (bf16; the fused decode scorer + selector + attention launch inside) against the REFERENCE module decoding
-    2200 tokens from an empty cache (nsa/core/nsa_attention.py:545-976), outputs of sampled steps; same bars as the prefill test"""
+    2200 tokens from an empty cache (nsa/core/nsa_attention.py:545-976), outputs and ranges of sampled steps; same gate as the prefill test"""
     import golden_inputs as gi
 
     g, m = _g19_module("sequential", torch.bfloat16)
     _, x_dec = gi.g19_inputs()
     x = torch.from_numpy(x_dec).cuda().bfloat16()
     rows = set(int(r) for r in g["rows_dec"])
-    outs = []
+    outs, rgs = [], []
     with torch.no_grad():
         kv = m.new_kv(x.shape[1], x.shape[0], "cuda", torch.bfloat16)
         for i in range(x.shape[0]):
             o, kv = m(x[i], kv, prefill=False)
             if i in rows:
                 outs.append(o.float())
+                rgs.append(m._last_ranges[0].clone())
     torch.cuda.synchronize()
     got = torch.stack(outs).cpu().numpy()
-    err, scale = _row_err(got, g["out_dec"])
-    tol = 1e-2 * max(scale, 1.0)
-    print(f"g19 decode: steps {err.size}, |ref| max {scale:.3f}, step err median {np.median(err):.2e} p90 {np.percentile(err, 90):.2e} "
-          f"max {err.max():.2e}; beyond {tol:.1e}: {(err > tol).mean():.4f}, beyond 4x: {(err > 4 * tol).mean():.4f}")
     assert np.isfinite(got).all() and kv.t == x.shape[0]
-    assert np.median(err) <= tol and np.percentile(err, 75) <= tol and (err > 4 * tol).mean() <= 0.10
+    err, scale = _row_err(got[:, 0, 0], g["out_dec"][:, 0, 0])
+    _g19_check("decode", err, scale, torch.stack(rgs).cpu().numpy(), g["ranges_dec"], g["gap_dec"], 0.5)
+    assert m.get_fallback_counters()["total_fallbacks"] == 0
+
+
+# ---- BASELINE configs[0] at its exact shape (g20): bench/bench_decode.py's CLI defaults ---------------------------------------------
+@pytest.mark.parametrize("selector", ["sequential", "batched"])
+def test_tiny_bench_shape_matches_reference_module(selector):
+    """BASELINE configs[0] ("configs/base.yaml tiny shape, S=512 ... via bench/bench_decode.py") at the bench's exact CLI defaults
+    (bench/bench_decode.py:63-72: dim 256, 8 heads, G 2, d_k = d_v 32, l 32, d 16, l' 64, n 16, w 512): the REFERENCE module (CPU fp32,
+    NSA_FORCE_SEL_MASK=1, gate on the selected branch) against this module in fp32 on the GPU -- prefill of the 512-token context in the given
+    selector mode (every row), then 512 + 32 decode steps from an empty cache (the bench's 32 steps sit behind a 512-token context; every
+    step): outputs within 1e-3 (north_star's fp32 bar), ranges identical.  With n = 16 >= S_sel = 8 / 9 blocks every complete block is
+    selected, so the ranges carry no near-tie freedom at this shape; d_k = 32 runs the generic (non-MFMA) kernels."""
+    import golden_inputs as gi
+    from nsa_vibe_amd.nsa_attention import NSAAttention
+
+    g = load_golden("g20_tiny_bench_module")
+    dim, H, G, dk, dv, l, d, ls, n, w = (int(x) for x in g["cfg"])
+    assert (dim, H, G, dk, dv, l, d, ls, n, w) == (256, 8, 2, 32, 32, 32, 16, 64, 16, 512)  # bench/bench_decode.py:63-72
+    m = NSAAttention(dim, H, G, dk, dv, l=l, d=d, l_sel=ls, n_sel=n, w=w, selector=selector)
+    names_shapes = [(str(nm), tuple(int(x) for x in sh if x > 0)) for nm, sh in zip(g["names"], g["shapes"])]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gi.g20_state(names_shapes).items()})
+    with torch.no_grad():
+        m.gate.fc2.bias.copy_(torch.tensor([-1000.0, 1000.0, -1000.0]))
+    m = m.cuda().eval()
+    x_pre, x_dec = (torch.from_numpy(a).cuda() for a in gi.g20_inputs())
+    tag = "seq" if selector == "sequential" else "bat"
+    with torch.no_grad():
+        out, _ = m(x_pre, m.new_kv(1, gi.G20_S_PRE, "cuda", torch.float32), prefill=True)
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - g[f"out_pre_{tag}"]).max() <= 1e-3
+        got_r, ref_r = m._last_ranges[0].cpu().numpy(), g[f"ranges_pre_{tag}"]
+        assert all(_live(got_r[t, gg]) == _live(ref_r[t, gg]) for t in range(gi.G20_S_PRE) for gg in range(G))
+        if selector == "sequential":  # decode always selects sequentially: one run
+            kv = m.new_kv(1, gi.G20_N_DEC, "cuda", torch.float32)
+            worst = 0.0
+            for i in range(gi.G20_N_DEC):
+                o, kv = m(x_dec[i], kv, prefill=False)
+                worst = max(worst, float(np.abs(o.cpu().numpy() - g["out_dec"][i]).max()))
+                rr = m._last_ranges[0].cpu().numpy()
+                assert all(_live(rr[gg]) == _live(g["ranges_dec"][i, gg]) for gg in range(G)), i
+            assert worst <= 1e-3, worst
+            assert kv.t == gi.G20_N_DEC
     assert m.get_fallback_counters()["total_fallbacks"] == 0

@@ -255,3 +255,41 @@ def test_g19_recipe_and_fixture_are_consistent():
     assert np.array_equal(rows_pre, g["rows_pre"]) and np.array_equal(rows_dec, g["rows_dec"])
     assert g["out_pre_seq"].shape == (1, len(rows_pre), 768) and g["out_dec"].shape == (len(rows_dec), 1, 1, 768)
     assert np.isfinite(g["out_pre_seq"]).all() and np.isfinite(g["out_pre_bat"]).all() and np.isfinite(g["out_dec"]).all()
+    # round 4: the reference's own selection per sampled row (ranges + the 13th / 14th ranking-key gap of its scores)
+    for tag, rows, W in (("pre_seq", rows_pre, 16), ("pre_bat", rows_pre, 16), ("dec", rows_dec, 16)):
+        assert g[f"ranges_{tag}"].shape == (len(rows), 2, W, 2) and g[f"gap_{tag}"].shape == (len(rows), 2)
+        assert (g[f"gap_{tag}"] >= 0).all()
+    # the reference's ranges obey the path's invariants: block 0 forced, nothing beyond t + 1, live ranges ascending and disjoint
+    for tag, rows in (("pre_seq", rows_pre), ("dec", rows_dec)):
+        for i, t in enumerate(rows):
+            for gg in range(2):
+                live = [(int(a), int(b)) for a, b in g[f"ranges_{tag}"][i, gg] if b > a]
+                assert live and live[0][0] == 0 and live[-1][1] == t + 1, (tag, t)
+                assert all(live[k][1] < live[k + 1][0] for k in range(len(live) - 1)), (tag, t)
+
+
+def test_g20_tiny_bench_shape_selection_matches_the_oracle_selector(orc):
+    """BASELINE configs[0] at the exact defaults of bench/bench_decode.py:63-72 (g20 = the reference MODULE at that shape): with n = 16 >= the
+    8 selection blocks of a 512-token context the selection takes every complete block, whatever the scores -- the oracle's two selectors on
+    arbitrary scores must give the ranges the reference module produced inside its forward, row for row (sequential: :124-249; batched:
+    :255-362 + :434-605), and the recipe must be bf16-representable like g19's"""
+    import torch
+
+    g = load_golden("g20_tiny_bench_module")
+    assert tuple(int(x) for x in g["cfg"]) == (256, 8, 2, 32, 32, 32, 16, 64, 16, 512)
+    S = gi.G20_S_PRE
+    meta = orc.build_block_meta(S, 32, 16, 64, 16, 512)
+    S_sel = meta.sel_starts.size
+    p = np.random.default_rng(20).random((1, S, 2, S_sel), dtype=np.float32)
+    bat = orc.select_topn_ranges_batched(p, meta, 16, S)[0]
+    assert bat.shape == g["ranges_pre_bat"].shape
+    live = lambda r: [(int(a), int(b)) for a, b in r if b > a]  # noqa: E731
+    for t in range(S):
+        seq = orc.select_topn_ranges(p[:, t], meta, 16, t)[0]
+        for gg in range(2):
+            assert live(seq[gg]) == live(g["ranges_pre_seq"][t, gg]), t
+            assert live(bat[t, gg]) == live(g["ranges_pre_bat"][t, gg]), t
+    names_shapes = [(str(nm), tuple(int(x) for x in sh if x > 0)) for nm, sh in zip(g["names"], g["shapes"])]
+    for k, v in gi.g20_state(names_shapes).items():
+        assert np.array_equal(torch.from_numpy(v).bfloat16().float().numpy(), v), k
+    assert g["out_pre_seq"].shape == (1, S, 256) and g["out_dec"].shape == (gi.G20_N_DEC, 1, 1, 256)
