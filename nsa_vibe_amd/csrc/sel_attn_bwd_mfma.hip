@@ -313,8 +313,9 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P,
     const int b = bg / P.G, g = bg - b * P.G;
     const int tw0 = grp * tpw, ntok = min(tpw, P.S - tw0);
 
-    unsigned char *k_row = smem + (size_t)wave * wave_lds;  // K, row image
-    unsigned char *k_tr = k_row + TILE;                     // K, transposable image
+    // ONE K image (round 4): the chunk-swizzled image of the transposing reads also serves the b128 row-fragment reads without bank
+    // conflicts (see bwd_dkdv_kernel), so K is fetched once per tile, not twice: 8 instead of 12 LDS-DMA instructions per 32 keys
+    unsigned char *k_tr = smem + (size_t)wave * wave_lds;   // K, transposable image (row fragments are read from it too)
     unsigned char *v_row = k_tr + TILE;                     // V, row image
     int *rg = (int *)(v_row + TILE);                        // [tpw][n][2]
     unsigned *fullw = (unsigned *)(rg + ((2 * tpw * n + 3) & ~3));
@@ -385,17 +386,19 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P,
     const unsigned char *Vb = (const unsigned char *)((const T *)P.V + (int64_t)b * P.vsb + (int64_t)g * P.vsg);
     const int64_t krowb = P.kss * 2, vrowb = P.vss * 2;
     const int ld_row = lane >> 3, ld_piece = lane & 7;
-    uint32_t kd_row[4], kd_tr[4], vd_row[4];
+    uint32_t kd_tr[4], vd_row[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 8 * i + ld_row;
-        kd_row[i] = (uint32_t)(ld_row * krowb + ((ld_piece ^ bswz_row(r)) << 4));
         kd_tr[i] = (uint32_t)(ld_row * krowb + (((((ld_piece >> 1) ^ bswz_tr(r)) << 1) | (ld_piece & 1)) << 4));
         vd_row[i] = (uint32_t)(ld_row * vrowb + ((ld_piece ^ bswz_row(r)) << 4));
     }
-    uint32_t rd_row[2], rd_tr[4];
+    uint32_t rd_row[2], rd_krow[2], rd_tr[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) rd_row[s] = off_row_img(rho, 4 * s + q);
+    for (int s = 0; s < 2; ++s) {
+        rd_row[s] = off_row_img(rho, 4 * s + q);
+        rd_krow[s] = off_tr_img(rho, 4 * s + q);
+    }
     {
         const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
 #pragma unroll
@@ -422,7 +425,6 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P,
             const int rowshift = whole ? 0 : (min(8 * i + ld_row, last) - ld_row);
             const int kso = whole ? ks + i * kstep : ks, vso = whole ? vs + i * vstep : vs;
             const uint32_t kadd = whole ? 0u : (uint32_t)(rowshift * krowb32), vadd = whole ? 0u : (uint32_t)(rowshift * vrowb32);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(k_row + i * 1024), 16, kd_row[i] + kadd, kso, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void *)(k_tr + i * 1024), 16, kd_tr[i] + kadd, kso, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void *)(v_row + i * 1024), 16, vd_row[i] + vadd, vso, 0, 0);
         }
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P,
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                kfr[u][s] = *(const x8 *)(k_row + rd_row[s] + u * 16 * BROWB);
+                kfr[u][s] = *(const x8 *)(k_tr + rd_krow[s] + u * 16 * BROWB);
                 vfr[u][s] = *(const x8 *)(v_row + rd_row[s] + u * 16 * BROWB);
             }
 #pragma unroll
@@ -582,14 +584,17 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
     constexpr int SLOTS = 16 * KB_NCT;        // (query,head) slots per round
     constexpr int IMG = SLOTS * BROWB;        // bytes of one staged image
     constexpr int NLD = SLOTS * 8 / 256;      // 16-byte pieces per thread and image
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * IMG];  // the K/V block images alias the staging images (only read before the loop)
+    // ONE image per staged operand (round 4): the chunk-swizzled image the transposing reads need serves the b128 row-fragment reads too, free
+    // of bank conflicts (every 16-lane service group of ds_read_b128 touches 64 distinct banks: checked exhaustively) -- rounds 1-3 staged
+    // Q and dO twice (row image + transposable image: 64 KiB of LDS writes per round instead of 32)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IMG];  // the K/V block images alias the staging images (only read before the loop)
     __shared__ __attribute__((aligned(16))) float s_lse2[SLOTS], s_delta[SLOTS];
     __shared__ __attribute__((aligned(16))) unsigned long long s_mask[SLOTS];
     __shared__ int s_tilefull[KB_NCT];  // every used slot of the tile covers all 64 keys of the block: the mask test is skipped
     __shared__ int s_t[512];
     __shared__ unsigned long long s_m[512];
     unsigned char *k_img = lds, *v_img = lds + 64 * BROWB;
-    unsigned char *q_row = lds, *q_tr = q_row + IMG, *do_row = q_tr + IMG, *do_tr = do_row + IMG;
+    unsigned char *q_img = lds, *do_img = lds + IMG;
 
 #ifdef NSA_DBG_WGTIME
     const unsigned long long dbg_t0 = wall_clock64();
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
     }
     uint32_t rd_row[2], rd_tr[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) rd_row[s] = off_row_img(rho, 4 * s + q);
+    for (int s = 0; s < 2; ++s) rd_row[s] = off_tr_img(rho, 4 * s + q);
     {
         const int qq = rho >> 2, pp = rho & 3, r = 4 * q + qq;
 #pragma unroll
@@ -724,10 +729,8 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
-                *(u32x4 *)(q_row + off_row_img(slot, pc)) = qa[i];
-                *(u32x4 *)(q_tr + off_tr_img(slot, pc)) = qa[i];
-                *(u32x4 *)(do_row + off_row_img(slot, pc)) = da[i];
-                *(u32x4 *)(do_tr + off_tr_img(slot, pc)) = da[i];
+                *(u32x4 *)(q_img + off_tr_img(slot, pc)) = qa[i];
+                *(u32x4 *)(do_img + off_tr_img(slot, pc)) = da[i];
             }
             if (tid < SLOTS) {
                 s_lse2[tid] = l2n;
@@ -741,41 +744,59 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
             }
             if (r0 + rows_per_round < nhit) fetch_round(r0 + rows_per_round);
             __syncthreads();
+            // column tiles go in PAIRS: the dV / dK products contract over the 32 (row, head) slots of two tiles with ONE 16x16x32 MFMA per
+            // 16 output columns (round 4: the 16x16x16 form they used costs the same issue cycles for half the work --
+            // tools/ubench/issue_rates.hip: 19-20 reported cycles either way; the MFMA's k index is only a label, so k = 8q + r is slot
+            // 4q + r of the first tile and k = 8q + 4 + r the same slot of the second, on both operands).  A second tile past the last
+            // hit row is all zero rows (p = 1 times zero dO, dS = 0): it adds nothing.
             const int ntile = min(KB_NCT, (min(nhit - r0, rows_per_round) * h + 15) >> 4);
-            for (int ct = 0; ct < ntile; ++ct) {
-                const int sbase = 16 * ct;
-                f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < ntile; ct += 2) {
+                x8 pa8, dsa8;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    S = M::mma32(*(const x8 *)(q_row + rd_row[s] + sbase * BROWB), kB[s], S);
-                    dP = M::mma32(*(const x8 *)(do_row + rd_row[s] + sbase * BROWB), vB[s], dP);
-                }
-                // accumulator rows = slots sbase + 4q + r, column = key 16 wave + rho
-                const f32x4 l2 = *(const f32x4 *)(s_lse2 + sbase + 4 * q);
-                const f32x4 dl = *(const f32x4 *)(s_delta + sbase + 4 * q);
-                // dS carries no `scale` here: dK is multiplied once when it is written (MFMA and VALU issue add up: every VALU instruction
-                // of this loop is paid in full).  Most tiles are fully covered (whole selection blocks): no per-key mask test for them.
-                x4 pa, dsa;
-                if (uniform(s_tilefull[ct])) {
+                for (int half = 0; half < 2; ++half) {
+                    const int sbase = 16 * (ct + half);
+                    f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r]));
-                        pa[r] = Elt<T>::from_f(p);
-                        dsa[r] = Elt<T>::from_f(p * (dP[r] - dl[r]));
+                    for (int s = 0; s < 2; ++s) {
+                        S = M::mma32(*(const x8 *)(q_img + rd_row[s] + sbase * BROWB), kB[s], S);
+                        dP = M::mma32(*(const x8 *)(do_img + rd_row[s] + sbase * BROWB), vB[s], dP);
                     }
-                } else {
+                    // accumulator rows = slots sbase + 4q + r, column = key 16 wave + rho
+                    const f32x4 l2 = *(const f32x4 *)(s_lse2 + sbase + 4 * q);
+                    const f32x4 dl = *(const f32x4 *)(s_delta + sbase + 4 * q);
+                    // dS carries no `scale` here: dK is multiplied once when it is written (MFMA and VALU issue add up: every VALU instruction
+                    // of this loop is paid in full).  Most tiles are fully covered (whole selection blocks): no per-key mask test for them.
+                    if (uniform(s_tilefull[ct + half])) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool cov = (s_mask[sbase + 4 * q + r] >> (16 * wave + rho)) & 1ull;
-                        const float p = cov ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r])) : 0.f;
-                        pa[r] = Elt<T>::from_f(p);
-                        dsa[r] = Elt<T>::from_f(p * (dP[r] - dl[r]));
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r]));
+                            pa8[4 * half + r] = Elt<T>::from_f(p);
+                            dsa8[4 * half + r] = Elt<T>::from_f(p * (dP[r] - dl[r]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool cov = (s_mask[sbase + 4 * q + r] >> (16 * wave + rho)) & 1ull;
+                            const float p = cov ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -l2[r])) : 0.f;
+                            pa8[4 * half + r] = Elt<T>::from_f(p);
+                            dsa8[4 * half + r] = Elt<T>::from_f(p * (dP[r] - dl[r]));
+                        }
                     }
                 }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    dV[n] = M::mma16(pa, tr_read<x4>(do_tr + rd_tr[n] + sbase * BROWB), dV[n]);
-                    dK[n] = M::mma16(dsa, tr_read<x4>(q_tr + rd_tr[n] + sbase * BROWB), dK[n]);
+                    const x4 d0 = tr_read<x4>(do_img + rd_tr[n] + 16 * ct * BROWB), d1 = tr_read<x4>(do_img + rd_tr[n] + 16 * (ct + 1) * BROWB);
+                    const x4 q0 = tr_read<x4>(q_img + rd_tr[n] + 16 * ct * BROWB), q1 = tr_read<x4>(q_img + rd_tr[n] + 16 * (ct + 1) * BROWB);
+                    x8 db, qb;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        db[jj] = d0[jj];
+                        db[4 + jj] = d1[jj];
+                        qb[jj] = q0[jj];
+                        qb[4 + jj] = q1[jj];
+                    }
+                    dV[n] = M::mma32(pa8, db, dV[n]);
+                    dK[n] = M::mma32(dsa8, qb, dK[n]);
                 }
             }
             __syncthreads();
@@ -918,7 +939,7 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
         const int nw = ((P.S_kv + 31) / 32 + 31) / 32;
         if (tpw >= 2 && P.S >= 2 * tpw && P.n >= 1 && P.n <= 64 && nw <= 128) {
             const int rg_ints = (2 * tpw * P.n + 3) & ~3, bm_ints = (2 * tpw * nw + 16 + 3) & ~3;
-            const int wave_lds = 3 * 32 * BROWB + 4 * (rg_ints + bm_ints);
+            const int wave_lds = 2 * 32 * BROWB + 4 * (rg_ints + bm_ints);
             const int64_t nbg2 = P.R / P.S, ngrp = (P.S + tpw - 1) / tpw, W4 = (ngrp + 3) / 4;
             NSA_CHECK_ARG(nbg2 * W4 < ((int64_t)1 << 31) && 4 * (size_t)wave_lds <= 160 * 1024, "bwd_dq_rows: launch too large");
             if (4 * (size_t)wave_lds > 64 * 1024)

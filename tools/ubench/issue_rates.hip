@@ -195,6 +195,13 @@ __global__ __launch_bounds__(256) void k(float *out) {
             asm volatile(REP8("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n") : "+v"(a0), "+v"(a1) : "v"(b0), "v"(c0));
         } else if (PAT == 29) {  // ONE chain of 4 dependent MFMA 32x32x16
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(w0) : "v"(fa), "v"(fb));
+        } else if (PAT == 33) {  // 4 independent MFMA 16x16x16 bf16 (the legacy half-K form the backward's dV / dK products use)
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            const s16x4 ha = __builtin_bit_cast(s16x4, (f32x4){a0, a1, 0, 0}.xy), hb = __builtin_bit_cast(s16x4, (f32x4){a2, a3, 0, 0}.xy);
+            m0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha, hb, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hb, ha, m1, 0, 0, 0);
+            m2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha, ha, m2, 0, 0, 0);
+            m3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hb, hb, m3, 0, 0, 0);
         } else if (PAT == 30) {  // ONE chain of 4 dependent MFMA 16x16x32
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n" : "+v"(m0) : "v"(fa), "v"(fb));
         } else if (PAT == 31) {  // three chains of 4 dependent MFMA 32x32x16, chain after chain (12 MFMA)
@@ -257,6 +264,7 @@ int main() {
     run<1>("8 x v_exp_f32", 8, out, ghz, n);
     run<2>("4 x v_pk_fma_f32", 4, out, ghz, n);
     run<3>("4 x mfma 16x16x32 bf16", 4, out, ghz, n);
+    run<33>("4 x mfma 16x16x16 bf16 (legacy half-K form)", 4, out, ghz, n);
     run<4>("4 x mfma + 8 x fma", 12, out, ghz, n);
     run<5>("4 x mfma + 16 x fma", 20, out, ghz, n);
     run<6>("4 x mfma + 8 x exp", 12, out, ghz, n);
