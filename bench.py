@@ -271,7 +271,10 @@ def band_bench(nv, B, S, device, iters=5):
 
 
 def backward_bench(nv, meta, Q, K, V, S, iters=5):
-    """selection attention forward + backward (autograd through the HIP kernels) on the bench workload"""
+    """selection attention forward + backward (autograd through the HIP kernels) on the bench workload, with the backward's roofline:
+    algorithmic flops 10*h*L*D per row (S = Q K^T, dP = dO V^T, dV = P^T dO, dK = dS^T Q, dQ = dS K: five products of 2*h*L*D; the analytic
+    backward of nsa/kernels/triton_sel_kernel/__init__.py:163-231) against the dense bf16 MFMA peak.  The kernels recompute S and dP in both the
+    query-major dQ pass and the key-block-major dK/dV pass (14*h*L*D issued): no atomics, bitwise reproducible."""
     B = Q.shape[0]
     g = torch.Generator(device=Q.device)
     g.manual_seed(6)
@@ -291,7 +294,14 @@ def backward_bench(nv, meta, Q, K, V, S, iters=5):
         if i >= 2:
             tf += a.elapsed_time(b) / iters
             tb += b.elapsed_time(c) / iters
-    return {"fwd_ms": tf, "bwd_ms": tb}
+    L = float((rg[..., 1] - rg[..., 0]).clamp_min(0).sum().item())
+    fl = 10.0 * H * L * D
+    tfl = fl / (tb * 1e-3) / 1e12
+    return {"fwd_ms": tf, "bwd_ms": tb, "bwd_over_fwd": tb / tf,
+            "roofline_bwd": {"kernel": "bwd_delta + bwd_dq_rows + bwd_hitmap + bwd_dkdv + bwd_reduce (the backward launches of one selection_attention_hip call)",
+                             "bound": "mfma", "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS,
+                             "algorithmic_flops": fl, "issued_flops_with_recompute": 1.4 * fl, "kernel_ms": tb,
+                             "traffic": pmc_traffic(f"sel_bwd_S{S}_B{B}")}}
 
 
 def layer_bench(nv, B, S, device, steps=40):

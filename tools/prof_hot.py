@@ -2,6 +2,7 @@
 """Focused workloads for rocprofv3 passes (kernel trace or PMC): the hot path of bench.py at one shape, a few launches.
 
     ... -- python3 tools/prof_hot.py prefill <S> <B> <iters> [attn|scores|select|all]     (select + attend launch / scorer / both)
+    ... -- python3 tools/prof_hot.py bwd <S> <B> <iters>                           (selection attention forward + backward, autograd)
     ... -- python3 tools/prof_hot.py decode  <B> <S_ctx> <iters>                   (nsa_sel_decode_step, the same cache every step: warm)
     ... -- python3 tools/prof_hot.py decode_cold <B> <S_ctx> <iters>               (the steps rotate over bench.py's independent cache sets: cold)
 """
@@ -30,6 +31,18 @@ if mode == "prefill":
             nv.select_and_attend(p, Q, K, V, meta, bench.N_SEL, mode="batched")
         if stage == "select":
             nv.select_topn_ranges_batched(p, meta, bench.N_SEL, S)
+    torch.cuda.synchronize()
+elif mode == "bwd":  # selection attention forward + backward on the bench's backward workload (bench.backward_bench)
+    S, B, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    meta, Q, Kc, K, V = bench.make_inputs(nv, B, S, dev, 99)
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    rg = nv.select_topn_ranges_batched(torch.rand(B, S, bench.G, meta.S_sel, device=dev, generator=g), meta, bench.N_SEL, S)
+    dO = torch.randn(Q.shape, device=dev, generator=g).bfloat16()
+    q, k, v = (x.clone().requires_grad_(True) for x in (Q, K, V))
+    for _ in range(iters + 1):
+        q.grad = k.grad = v.grad = None
+        nv.selection_attention_hip(q, k, v, rg).backward(dO)
     torch.cuda.synchronize()
 elif mode == "decode_cold":
     B, S, iters = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
