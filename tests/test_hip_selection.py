@@ -796,6 +796,39 @@ def test_decode_step_one_pass_form(nv, orc, tune, S_ctx, B, h):
     assert n_checked >= B * G  # the gate must not be vacuous (random rows: gaps of 1e-2 .. 1e-4 relative)
 
 
+def test_decode_step_at_the_large_batch_64k_shape_the_plan_gives_the_one_pass_form(nv, tune):
+    """B = 128 sequences at a 64k context (256 rows x 64 chunks: a team of workgroups per row would not fit the chip, so the automatic plan
+    takes the one-pass form; bench.py's decode_B128_S65536 / decode_B256_S65536 lines run it): every row against the exact round-2 kernels
+    (DECODE_STEP = 0: logits in LDS, two launches) -- ranges identical wherever the 13th / 14th keys are decided by more than the form's score
+    noise (relative 1e-5 against <= 2.4e-7), O identical on those rows up to the different merge grouping (8 vs 16 waves: <= 1 bf16 ulp), and
+    run-to-run bit-identical.  K/V 4 GiB."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(128)
+    B, G, h, D, n, S_ctx = 128, 2, 6, 64, 16, 65536
+    meta = nv.build_block_meta(S_ctx, 32, 16, 64, n, 512)
+    mk = lambda *sh: torch.randn(*sh, device="cuda", generator=g, dtype=torch.bfloat16)  # noqa: E731
+    Q, Kc, K, V = mk(B, 1, G, h, D), mk(B, G, meta.S_cmp, D), mk(B, G, S_ctx, D), mk(B, G, S_ctx, D)
+    t = S_ctx - 1
+    O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    O2, r2 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    tune("DECODE_STEP", 0)
+    O0, r0 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2) and torch.equal(O1, O2)
+    p = nv.selection_scores(Q, Kc, meta)[:, 0]
+    cand = p.clone()
+    cur = t // 64
+    cand[..., 0] = -1
+    cand[..., cur - 1:] = -1
+    top = cand.topk(n - 3 + 1, dim=-1).values
+    gated = (top[..., n - 4] - top[..., n - 3]) > 1e-5 * top[..., n - 4].abs()
+    assert gated.float().mean().item() > 0.9
+    assert torch.equal(r0[gated], r1[gated])
+    assert (O0[:, 0][gated].float() - O1[:, 0][gated].float()).abs().max().item() <= 1.6e-2
+    same = (r0 == r1).all(dim=-1).all(dim=-1)
+    print(f"one-pass form at B=128 @64k: rows {same.numel()}, gated {int(gated.sum())}, rows with the exact form's ranges {int(same.sum())}")
+
+
 @pytest.mark.parametrize("h", [1, 3, 4, 8, 16])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_decode_step_kernel_other_group_sizes(nv, tune, h, dtype):
