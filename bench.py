@@ -14,21 +14,23 @@ Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequence
 path (weak scaling); time = max over ranks.
 
 The JSON line also carries
-  roofline         dominant kernel of the step (the selection-attention kernel; the step is three launches: scores, select,
-                   attention).  In prefill every K/V row is gathered many times:
-                   at S=65536 a (b,g)'s K/V (16 MiB) exceeds an XCD's 4 MiB L2, a third of the gathered bytes miss, and the launch is
-                   bound by that L2-miss traffic -- bound "hbm": HBM-side bytes per launch (rocprofv3 PMC, profiles/r02/traffic_*.json,
-                   same shape) / HIP-event kernel time vs the 8 TB/s peak.  The algorithmic gather rate (> peak: cache reuse), the
-                   gathered bytes vs the aggregate L2 bandwidth (`l2`) and the in-block MFMA fraction (`mfma`) sit beside it.  Shapes
-                   whose K/V fits L2 (S <= 16k) report bound "l2".
+  roofline         dominant kernel of the step (the selection-attention launches; the step is three launches: scores, select, attention, plus
+                   the merge launch of the key-split form from 32k keys on).  Top level = the roof SURVEY 8(d) names for the timed (prefill)
+                   form: in-block QK^T + PV flops against the dense bf16 MFMA peak, a fraction <= 1 (qk_frac = the QK^T half).  The
+                   memory-side views sit beside it, nested and as scalar keys: hbm_traffic_frac (rocprofv3 PMC bytes, profiles/r0x/traffic_*.json,
+                   same shape, / HIP-event time vs 8 TB/s), l2_frac (the 64-key blocks the waves bring into LDS vs the ~34.5 TB/s aggregate);
+                   algorithmic_gather_GBps (SURVEY 8(d)'s byte formula / time: above the HBM peak, L2 re-use) is a plain field.
   decode_roofline  the HBM-bound configuration north_star names: one decode step of B sequences at context S reads
                    sum_rows L_row*(Dk+Dv)*2 B of selected K/V plus the compressed keys (S_cmp*Dk*2 B per (b,g)) exactly once
                    (reads formula of nsa/core/nsa_attention.py:634-635, bytes formula of triton_sel_kernel/__init__.py:483);
-                   achieved = those bytes / step time vs the 8 TB/s HBM peak.
+                   achieved = those bytes / COLD step time vs the 8 TB/s HBM peak.  Cold = the steps rotate over independent cache sets
+                   (>= 512 MiB loaded between two uses of a line); the warm figure (same set back to back: Infinity-Cache served) is kept
+                   beside it.  Top level = the S = 65536 configuration with the highest cold fraction; every shape is in `extra`.
   cpu_baseline     the CPU oracle (a port of the reference path, validated against the reference) timed on this node's host
                    cores on a bounded sample of the same workload
-  extra            decode tok/s and prefill ms at S in {4k,16k,64k} of the hot path, MFMA TFLOP/s of the attention kernel,
-                   selection backward, the sliding/compressed branch kernel, and the whole NSAAttention layer (native path)
+  library          path and sha256 of the libnsa_sel_hip.so that ran (NSA_HIP_LIB can point a measurement at an A/B build)
+  extra            decode tok/s (cold) and prefill ms at S in {4k,16k,64k} of the hot path, MFMA TFLOP/s of the attention kernel,
+                   selection backward with its roofline, the sliding/compressed branch kernel, and the whole NSAAttention layer (native path)
 """
 import argparse
 import json
