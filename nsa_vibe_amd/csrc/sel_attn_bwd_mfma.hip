@@ -696,6 +696,9 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
         float l2n = 0.f, dln = 0.f;
         unsigned long long mkn = 0ull;
         auto fetch_round = [&](int r0) {
+#ifdef DKDV_NOFETCH  // ablation (timing only): no global loads of Q / dO rows
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int p = tid + 256 * i, slot = p >> 3, pc = p & 7;
@@ -749,7 +752,11 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
             // tools/ubench/issue_rates.hip: 19-20 reported cycles either way; the MFMA's k index is only a label, so k = 8q + r is slot
             // 4q + r of the first tile and k = 8q + 4 + r the same slot of the second, on both operands).  A second tile past the last
             // hit row is all zero rows (p = 1 times zero dO, dS = 0): it adds nothing.
+#ifdef DKDV_NOCOMPUTE  // ablation (timing only, results meaningless): staging and bookkeeping without the tile loop
+            const int ntile = 0;
+#else
             const int ntile = min(KB_NCT, (min(nhit - r0, rows_per_round) * h + 15) >> 4);
+#endif
             for (int ct = 0; ct < ntile; ct += 2) {
                 x8 pa8, dsa8;
 #pragma unroll
