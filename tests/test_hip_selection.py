@@ -895,6 +895,17 @@ def test_decode_step_on_tie_heavy_scores(nv, orc, tune, S_ctx):
             torch.cuda.synchronize()
             assert torch.equal(r0, r1), (nw, ns)
     tune("DECODE_WAVES", -1), tune("DECODE_SPLIT", -1)
+    # the one-pass form (DECODE_WIDE = 2) on the rows its contract covers: the peaked softmax (most scores exact zeros in both forms), the
+    # ordinary row and the NaN row (every score NaN: no candidate, forced blocks only) must give the exact forms' ranges; the all-tie and
+    # plateau rows are what only the exact forms guarantee (their scores are equal up to the last bit, which the extra rounding can move)
+    if meta.S_cmp <= 64 * 8 * 8:
+        tune("DECODE_WIDE", 2)
+        for nw in (16, 8):
+            tune("DECODE_WAVES", nw)
+            O2, r2 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
+            torch.cuda.synchronize()
+            assert torch.equal(r0[2:], r2[2:]), nw
+        tune("DECODE_WIDE", -1), tune("DECODE_WAVES", -1)
     O1, r1 = nv.selection_decode_step(Q, Kc, K, V, meta, n, t)
     fin = torch.isfinite(O0.float()).all(dim=-1).all(dim=-1)
     assert torch.equal(O0[fin], O1[fin])
