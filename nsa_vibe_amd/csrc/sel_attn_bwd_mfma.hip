@@ -563,8 +563,8 @@ __device__ unsigned long long g_dbg[4 * 65536];
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, const float *__restrict__ delta, float *__restrict__ part,
-                                                        const unsigned long long *__restrict__ hitmap, int *__restrict__ flags,
-                                                        int rows_per_split, int nkb, int nbg, int nsplit) {
+                                                        const unsigned long long *__restrict__ hitmap, const unsigned long long *__restrict__ fullmap,
+                                                        int *__restrict__ flags, int rows_per_split, int nkb, int nbg, int nsplit) {
     using M = BwdT<T>;
     using x8 = typename M::x8;
     using x4 = typename M::x4;
@@ -646,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
     const int row_begin = zsp * rows_per_split, row_end = min(P.S, row_begin + rows_per_split);
     const int wpb = (P.S + 63) >> 6;  // hit-map words per (bg, key block)
     const unsigned long long *hm = hitmap + ((int64_t)bg * nkb + j) * wpb;
+    const unsigned long long *hf = fullmap + ((int64_t)bg * nkb + j) * wpb;
     // Hits are collected over 256-row chunks until at least 256 are pending (far-away key blocks see a handful of hits per
     // chunk at long context; staging rounds want to be full)
     int total_hits = 0, pend = 0;
@@ -668,14 +669,19 @@ __global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(SelAttnBwdParams P, co
             if (w < wave) off += __popcll(hw[w]);
             if (w == wave) hitb = hw[w];
         }
+        const int wi_own = (base >> 6) + wave;
+        const unsigned long long fullb = wi_own < wpb ? hf[wi_own] : 0ull;  // rows whose hit is one range over the whole block: mask known
         if ((hitb >> lane) & 1ull) {
             const int t = base + tid;
-            unsigned long long mask = 0ull;
-            const int32_t *rg = P.ranges + (((int64_t)b * P.S + t) * P.G + g) * (int64_t)P.n * 2;
-            for (int i = 0; i < P.n; ++i) {
-                int s0 = min(max(rg[2 * i], 0), P.S_kv), e0 = min(max(rg[2 * i + 1], 0), P.S_kv);
-                const int lo = max(s0, key0) - key0, hi = min(e0, key0 + 64) - key0;
-                if (hi > lo) mask |= ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+            unsigned long long mask = ~0ull;
+            if (!((fullb >> lane) & 1ull)) {  // partial coverage (or several ranges inside the block): the key mask from the row's ranges
+                mask = 0ull;
+                const int32_t *rg = P.ranges + (((int64_t)b * P.S + t) * P.G + g) * (int64_t)P.n * 2;
+                for (int i = 0; i < P.n; ++i) {
+                    int s0 = min(max(rg[2 * i], 0), P.S_kv), e0 = min(max(rg[2 * i + 1], 0), P.S_kv);
+                    const int lo = max(s0, key0) - key0, hi = min(e0, key0 + 64) - key0;
+                    if (hi > lo) mask |= ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+                }
             }
             const int pos = off + __popcll(hitb & ((1ull << lane) - 1ull));
             s_t[pos] = t;
@@ -864,8 +870,12 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float *__restrict
 // Inverted index of the selection: hitmap[bg][key block j][t / 64] bit (t % 64) = row t of (b,g) has a range reaching into
 // keys [64 j, 64 j + 64).  One wave = the 64 rows of one word: lanes that reach the same block are gathered with a ballot, so
 // a word gets one OR per (range slot, block) instead of one per row; OR-ing makes the result independent of the order.
+// fullmap (same shape, round 4): bit = ONE range of the row covers all 64 keys of the block.  The dK/dV kernel then knows the row's key mask
+// of the block (all ones) without reading the row's ranges -- every hit of a batched selection (whole blocks only), all but the clamped last
+// block of a sequential one, the inner blocks of a band.
 __global__ __launch_bounds__(256) void bwd_hitmap_kernel(const int32_t *__restrict__ ranges, unsigned long long *__restrict__ hitmap,
-                                                          int64_t nwords, int S, int G, int n, int S_kv, int nkb) {
+                                                          unsigned long long *__restrict__ fullmap, int64_t nwords, int S, int G, int n, int S_kv,
+                                                          int nkb) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= nwords) return;
@@ -875,6 +885,7 @@ __global__ __launch_bounds__(256) void bwd_hitmap_kernel(const int32_t *__restri
     const int64_t b = bg / G, g = bg - b * G;
     const int32_t *rg = ranges + ((b * S + min(t, S - 1)) * G + g) * (int64_t)n * 2;
     unsigned long long *w = hitmap + bg * nkb * wpb + tw;
+    unsigned long long *wf = fullmap + bg * nkb * wpb + tw;
     for (int i = 0; i < n; ++i) {
         const int s0 = min(max(rg[2 * i], 0), S_kv), e0 = min(max(rg[2 * i + 1], 0), S_kv);
         int j = s0 >> 6;
@@ -886,7 +897,11 @@ __global__ __launch_bounds__(256) void bwd_hitmap_kernel(const int32_t *__restri
             const int j0 = __shfl(j, src);
             const bool mine = j <= jend && j == j0;
             const unsigned long long m = __ballot(mine);
-            if (lane == src) atomicOr(w + (int64_t)j0 * wpb, m);
+            const unsigned long long mf = __ballot(mine && s0 <= 64 * j0 && e0 >= 64 * j0 + 64);
+            if (lane == src) {
+                atomicOr(w + (int64_t)j0 * wpb, m);
+                if (mf) atomicOr(wf + (int64_t)j0 * wpb, mf);
+            }
             if (mine) ++j;
         }
     }
@@ -902,9 +917,9 @@ bool sel_attn_bwd_mfma_supported(int dtype, int h, int Dk, int Dv) {
     return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && Dk == 64 && Dv == 64 && h >= 1 && h <= 16;
 }
 
-// workspace layout: delta [R*h] f32 | hit map [nbg][nkb][ceil(S/64)] u64 | flags [ns][nbg][nkb] i32 | ns partial [dK|dV] slabs
+// workspace layout: delta [R*h] f32 | hit map [nbg][nkb][ceil(S/64)] u64 | full map (same shape) | flags [ns][nbg][nkb] i32 | ns partial [dK|dV] slabs
 struct BwdWs {
-    size_t hitmap, flags, part, total, hitmap_bytes;
+    size_t hitmap, fullmap, flags, part, total, hitmap_bytes;
     int ns, nkb;
 };
 static BwdWs bwd_ws_layout(int64_t R, int h, int S, int64_t nbg, int S_kv) {
@@ -914,7 +929,8 @@ static BwdWs bwd_ws_layout(int64_t R, int h, int S, int64_t nbg, int S_kv) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     w.hitmap = up(sizeof(float) * (size_t)R * h);
     w.hitmap_bytes = sizeof(unsigned long long) * (size_t)nbg * w.nkb * ((S + 63) / 64);
-    w.flags = w.hitmap + up(w.hitmap_bytes);
+    w.fullmap = w.hitmap + up(w.hitmap_bytes);
+    w.flags = w.fullmap + up(w.hitmap_bytes);
     w.part = w.flags + up(sizeof(int) * (size_t)w.ns * nbg * w.nkb);
     w.total = w.part + (w.ns > 1 ? sizeof(float) * (size_t)w.ns * 2 * (size_t)nbg * S_kv * BD : 0);
     return w;
@@ -966,17 +982,18 @@ static int launch_bwd_t(const SelAttnBwdParams &P, float *delta, hipStream_t st)
     const int rows_per_split = ((P.S + ns - 1) / ns + 255) / 256 * 256;
     unsigned char *ws = (unsigned char *)delta;
     unsigned long long *hitmap = (unsigned long long *)(ws + W.hitmap);
+    unsigned long long *fullmap = (unsigned long long *)(ws + W.fullmap);
     int *flags = (int *)(ws + W.flags);
     float *part = (float *)(ws + W.part);
-    NSA_HIP_TRY(hipMemsetAsync(hitmap, 0, W.hitmap_bytes, st));
+    NSA_HIP_TRY(hipMemsetAsync(hitmap, 0, W.fullmap - W.hitmap + W.hitmap_bytes, st));  // both maps (adjacent)
     const int64_t nwords = nbg * ((P.S + 63) / 64);
-    hipLaunchKernelGGL(bwd_hitmap_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, st, P.ranges, hitmap, nwords, P.S, P.G, P.n,
-                       P.S_kv, W.nkb);
+    hipLaunchKernelGGL(bwd_hitmap_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, st, P.ranges, hitmap, fullmap, nwords, P.S, P.G,
+                       P.n, P.S_kv, W.nkb);
     NSA_LAUNCH_CHECK("bwd_hitmap");
     const int64_t ngrid = ((nbg * ns + 7) / 8) * 8 * W.nkb;
     NSA_CHECK_ARG(ngrid < ((int64_t)1 << 31), "bwd: too many key-block workgroups for one launch");
     hipLaunchKernelGGL(bwd_dkdv_kernel<T>, dim3((unsigned)ngrid), dim3(256), 0, st, P, (const float *)delta, part,
-                       (const unsigned long long *)hitmap, flags, rows_per_split, W.nkb, (int)nbg, ns);
+                       (const unsigned long long *)hitmap, (const unsigned long long *)fullmap, flags, rows_per_split, W.nkb, (int)nbg, ns);
     NSA_LAUNCH_CHECK("bwd_dkdv");
     if (ns > 1) {
         const int64_t slab = nbg * P.S_kv * BD;
