@@ -345,6 +345,11 @@ NSA_API int nsa_sel_select_attn_fwd(const float *p_grp, int t0, const int32_t *t
  *   (nsa/core/nsa_attention.py:651 compute_pcmp_all, :658 map_pcmp_to_pslc_batched, :670 head sum,
  *   :672 select_topn_ranges, :704-830 selection executor).
  *   ranges_out [B,G,n_top,2] int32, O [B,1,G,h,Dv]; workspace: nsa_sel_decode_step_workspace() bytes, 16-B aligned.
+ *   Kernel form (one launch wherever the default block geometry, bf16 / f16 and Dk = Dv = 64 allow): chosen from (B*G, S_cmp) -- logits
+ *   in registers for rows of up to 32 chunks of 64 compressed rows, a team of workgroups per row for longer rows while B*G teams fit the
+ *   chip, and for more rows than that (B >= 128 at a 64k context) the one-pass form, whose group scores carry one more rounding (<= 2 ulp)
+ *   than the other forms': its ranges are theirs wherever the (n_top - 3)-th and the next ranking key differ by more than that (tuning
+ *   switch "DECODE_WIDE": 0 = never, 1 = the exact one-workgroup form instead).  Every form is bitwise reproducible run to run.
  * ------------------------------------------------------------------------------------- */
 NSA_API size_t nsa_sel_decode_step_workspace(int B, int G, int h, int Dk, int Dv, int S_cmp, int S_sel, int n_top, int dtype);
 NSA_API int nsa_sel_decode_step(const void *Q, const void *K_cmp, const void *K, const void *V, const int32_t *csc_ptr,

@@ -5,7 +5,7 @@ import sys, os, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 import bench, nsa_vibe_amd as nv
 dev = torch.device("cuda", 0)
-for (B, S) in [(64, 65536), (1, 65536), (64, 16384), (256, 16384)]:
+for (B, S) in [(64, 65536), (1, 65536), (64, 16384), (256, 16384), (128, 65536), (200, 40000)]:  # (the last two: one-pass form)
     meta = nv.build_block_meta(S, 32, 16, 64, 16, 512)
     g = torch.Generator(device="cuda"); g.manual_seed(B + S)
     mk = lambda *s: torch.randn(*s, device="cuda", generator=g).bfloat16()
