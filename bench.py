@@ -5,7 +5,7 @@
 
 A "step" = one pass of the hot path over one batch of synthetic input for one layer:
     Q,K_cmp -> p_grp (softmax scores, Eq.9, Eq.10) -> deterministic top-n ranges -> selection attention
-(two launches: the fused scorer, then one kernel that selects the row's ranges and attends over them)
+(two launches + the merge launch of the key-split form: the fused scorer with the top-n selection in its epilogue, then the attention kernel)
 on the m7c_125m shape (dim 768: 12 heads, G=2, h=6, d_k=d_v=64; l=32 d=16 l'=64 n=16) at S=65536 (north_star's target
 length, BASELINE.json configs[3]), bf16, B=16 sequences per GPU: K/V = 512 MiB, twice the Infinity Cache, so the inputs
 really live in HBM.  Inputs are resident in HBM before the timed region.  (--seq/--batch select the other BASELINE shapes;
@@ -14,8 +14,8 @@ Multi-GPU: the batch x group axis is sharded, every rank runs its own B sequence
 path (weak scaling); time = max over ranks.
 
 The JSON line also carries
-  roofline         dominant kernel of the step (the selection-attention launches; the step is three launches: scores, select, attention, plus
-                   the merge launch of the key-split form from 32k keys on).  Top level = the roof SURVEY 8(d) names for the timed (prefill)
+  roofline         dominant kernel of the step (the selection-attention launches; the step is scores + select in one launch, then the attention
+                   and the merge launch of its key-split form from 32k keys on).  Top level = the roof SURVEY 8(d) names for the timed (prefill)
                    form: in-block QK^T + PV flops against the dense bf16 MFMA peak, a fraction <= 1 (qk_frac = the QK^T half).  The
                    memory-side views sit beside it, nested and as scalar keys: hbm_traffic_frac (rocprofv3 PMC bytes, profiles/r0x/traffic_*.json,
                    same shape, / HIP-event time vs 8 TB/s), l2_frac (the 64-key blocks the waves bring into LDS vs the ~34.5 TB/s aggregate);
@@ -64,11 +64,12 @@ def make_inputs(nv, B, S, device, seed):
 
 
 def hot_path(nv, meta, Q, Kc, K, V, S):
-    # causal_skip: scores of blocks that both selectors mask to -inf at row t are not computed
-    p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
-    # batched top-n (select_topn_ranges_batched semantics) + selection attention: one native call, the selector runs inside the
-    # attention launch; the ranges are still materialised (they are an output of the path)
-    return nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched")
+    # scores (blocks both selectors mask to -inf at row t are not computed) + batched top-n (select_topn_ranges_batched semantics) in ONE
+    # launch: a scorer workgroup selects the ranges of its 64 query rows right behind its second sweep (nsa_sel_scores_select) ...
+    p_grp, ranges = nv.selection_scores_select(Q, Kc, meta, N_SEL, mode="batched")
+    # ... then the selection attention over the ranges (they are an output of the path)
+    with torch.no_grad():
+        return ranges, nv.selection_attention_hip(Q, K, V, ranges)
 
 
 def time_events(fn, iters, warm=2):
@@ -91,12 +92,13 @@ def stage_times(nv, meta, Q, Kc, K, V, S, iters):
     p_grp = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
     ranges = nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S)
     t_sc = time_events(lambda: nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True), iters)
+    t_scsel = time_events(lambda: nv.selection_scores_select(Q, Kc, meta, N_SEL, mode="batched"), iters)
     t_sel = time_events(lambda: nv.select_topn_ranges_batched(p_grp, meta, N_SEL, S), iters)
     with torch.no_grad():
         t_att = time_events(lambda: nv.selection_attention_hip(Q, K, V, ranges), iters)
     t_sa = time_events(lambda: nv.select_and_attend(p_grp, Q, K, V, meta, N_SEL, mode="batched"), iters)
     L = (ranges[..., 1] - ranges[..., 0]).clamp_min(0).sum(-1).double()
-    return t_sc, t_sel, t_att, t_sa, float(L.sum().item()), float(L.mean().item()), gathered_tiles(ranges, K.shape[2])
+    return t_sc, t_sel, t_att, t_sa, float(L.sum().item()), float(L.mean().item()), gathered_tiles(ranges, K.shape[2]), t_scsel
 
 
 BLK_KEYS = 64                           # keys of one K/V block of the block-form kernel (sel_attn_blocks_mfma.hip)
@@ -755,7 +757,7 @@ def main():
 
     out["library"] = _nsa_lib.loaded_library()  # which build of libnsa_sel_hip.so ran (NSA_HIP_LIB can point at an A/B build: never the product figure)
     if rank == 0:
-        t_sc, t_sel, t_att, t_sa, Lsum, Lmean, n_tiles = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
+        t_sc, t_sel, t_att, t_sa, Lsum, Lmean, n_tiles, t_scsel = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
         gathered = n_tiles * BLK_KEYS * (D + D) * 2
         alg_bytes = Lsum * (D + D) * 2  # L_row * (Dk+Dv) * sizeof(bf16), K/V counted once per group
         flops = 4.0 * H * Lsum * D  # 2*h*L*Dk (QK^T) + 2*h*L*Dv (PV) per row
@@ -796,9 +798,11 @@ def main():
             v = out["roofline"][key]
             if v is not None and not (0.0 <= v <= 1.0):
                 raise SystemExit(f"bench.py: roofline.{key} = {v} is not a fraction of its roof; refusing to print the line")
-        out["stages_ms"] = {"scores": t_sc, "select": t_sel, "attention": t_att, "select_and_attention_one_call": t_sa,
-                            "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop, "
-                                    "so the stages can sum to slightly more.  The step is three launches: scores, select, attention"}
+        out["stages_ms"] = {"scores_and_select_one_launch": t_scsel, "attention": t_att, "scores_alone": t_sc, "select_alone": t_sel,
+                            "select_and_attention_one_call": t_sa,
+                            "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop.  "
+                                    "The step is scores + select in one launch (the selector runs in the scorer's epilogue), then the attention "
+                                    "launches; scores_alone / select_alone time the two kernels as separate launches for comparison"}
         flops_sc = 2.0 * B * S * G * H * meta.S_cmp * D
         out["roofline_scores"] = {"kernel": "scores_mfma32_kernel (fused p_cmp softmax + Eq.10 + Eq.9 on 32x32x16 tiles; 16x16 forms for other group sizes)", "bound": "mfma",
                                   "achieved": flops_sc / (t_sc * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -826,8 +830,8 @@ def main():
                 for S2, B2 in ((4096, 8), (4096, 1), (16384, 1), (65536, 1)):
                     m2, Q2, Kc2, K2, V2 = make_inputs(nv, B2, S2, device, 99)
                     ms = time_events(lambda: hot_path(nv, m2, Q2, Kc2, K2, V2, S2), 5, warm=2)
-                    sc, se, at, sa, Ls, Lm, nt2 = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 5)
-                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "tok_per_s": B2 * S2 / (ms * 1e-3), "scores_ms": sc, "select_ms": se,
+                    sc, se, at, sa, Ls, Lm, nt2, scs = stage_times(nv, m2, Q2, Kc2, K2, V2, S2, 5)
+                    extra[f"prefill_S{S2}_B{B2}"] = {"ms": ms, "tok_per_s": B2 * S2 / (ms * 1e-3), "scores_ms": sc, "select_ms": se, "scores_and_select_one_launch_ms": scs,
                                                     "attention_ms": at, "select_and_attention_ms": sa, "attn_alg_GBps": Ls * 256 / (at * 1e-3) / 1e9,
                                                     "attn_gathered_GBps": nt2 * BLK_KEYS * 256 / (at * 1e-3) / 1e9,
                                                     "attn_tflops": 4.0 * H * Ls * D / (at * 1e-3) / 1e12,

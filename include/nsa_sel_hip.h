@@ -70,7 +70,7 @@ NSA_API const char *nsa_hip_last_error(void);
 /* Measurement / A-B switches (kernel form, staging, mapping).  Each switch is seeded once per process from the environment
  * variable NSA_HIP_<NAME> and can be changed afterwards only through this call (nothing reads the environment on the launch
  * path).  name: "SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP" (TIMELINE builds
- * only), "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2" (with or without the NSA_HIP_ prefix); value -1 = automatic where the switch has an automatic setting.  Results never depend on a switch beyond the
+ * only), "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2", "SCORES_SELECT" (with or without the NSA_HIP_ prefix); value -1 = automatic where the switch has an automatic setting.  Results never depend on a switch beyond the
  * tolerances stated for the entry point. */
 NSA_API int nsa_hip_set_tuning(const char *name, int value);
 NSA_API int nsa_hip_get_tuning(const char *name, int *value);
@@ -324,6 +324,24 @@ NSA_API int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, 
                            int S_sel, int l_sel, int n_top, int force_init, int force_local, int mode,
                            int S_total /* batched: the S the forced-column rule is evaluated for */,
                            int32_t *ranges_out, int out_width, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Scores + top-n selection in one call (prefill; round 4): the arguments of nsa_sel_scores (variant 0) followed by those of
+ * nsa_select_topn_ranges (rows in the [B,S,G] order of Q, token of row (b,s,g) = t0 + s).  Replaces compute_pcmp_all ->
+ * map_pcmp_to_pslc_batched -> sum(dim=3) -> select_topn_ranges[_batched] (nsa/core/nsa_attention.py:1088-1108, 1566-1576;
+ * nsa/core/selection_scorer.py:42-61, 89-116, 124-249, 255-362).  Where the 32x32x16 MFMA scorer applies (h = 6, Dk = 64, default block
+ * geometry, bf16 / f16, S_sel <= 1024) a workgroup selects the ranges of its 64 query rows right behind its second sweep, with the select
+ * kernel's own row function: ONE launch, the scores are read back out of L2 (no HBM read of p_grp), the selector's scalar work runs beside
+ * the scorer's matrix / vector work.  Everywhere else the scorer and the select kernel are launched back to back.  p_grp is still written
+ * (same contract as nsa_sel_scores with the given causal_skip); ranges_out is bit-identical to the two separate calls either way.
+ * workspace: the larger of nsa_sel_scores_workspace(..., variant 0) and (..., variant 1) bytes (rows that are not 16-byte aligned take the
+ * generic scorer).
+ * ------------------------------------------------------------------------------------- */
+NSA_API int nsa_sel_scores_select(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp,
+                          int64_t kc_stride_b, int64_t kc_stride_g, int64_t kc_stride_s, const int32_t *csc_ptr, const int32_t *csc_rows,
+                          const float *csc_vals, int S_sel, int l, int d, int l_sel, int causal_skip, int dtype, float scale, int t0,
+                          int n_top, int force_init, int force_local, int mode, int S_total, int32_t *ranges_out, int out_width,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Top-n selection + selection attention in one call (prefill): the arguments of nsa_select_topn_ranges followed by those of

@@ -43,6 +43,7 @@ from .selection_scorer import (  # noqa: F401
     select_topn_ranges_batched,
     select_topn_ranges_rows,
     selection_scores,
+    selection_scores_select,
     validate_selection_determinism,
     verify_mapping_equivalence,
 )

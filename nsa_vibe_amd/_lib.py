@@ -82,6 +82,7 @@ SIGNATURES = {
     "nsa_pcmp_all": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_i, _f, _vp]),
     "nsa_sel_scores_workspace": (_sz, [_i] * 12),
     "nsa_sel_scores": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_vp, _vp, _vp] + [_i] * 7 + [_f, _vp, _sz, _vp]),
+    "nsa_sel_scores_select": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_i64] * 3 + [_vp, _vp, _vp] + [_i] * 6 + [_f] + [_i] * 6 + [_vp, _i, _vp, _sz, _vp]),
     "nsa_sel_decode_step_workspace": (_sz, [_i] * 9),
     "nsa_sel_decode_step": (_i, [_vp] * 9 + [_i] * 13 + [_i64] * 9 + [_i, _f, _vp, _sz, _vp]),
     "nsa_batched_ranges_width": (_i, [_i] * 6),

@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP", "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, -1, -1, -1, 0, -1, -1, 1, -1, -1, -1, -1};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP", "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2", "SCORES_SELECT"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, -1, -1, -1, 0, -1, -1, 1, -1, -1, -1, -1, -1};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -84,7 +84,7 @@ int launch_decode_scores(const void *, const void *, float *, int, int, int, int
                          const int32_t *, const int32_t *, const float *, int, int, float, void *, size_t, hipStream_t);
 bool scores_mfma_supported(int, int, int, int, int, int);
 int launch_sel_scores_mfma(const void *, const void *, float *, int, int, int, int, int, int, int64_t, int64_t, int64_t, int,
-                           int, int, float, int, hipStream_t);
+                           int, int, float, int, hipStream_t, const SelectParams *, int *);
 
 int launch_sel_first_key(const void *, const int32_t *, void *, int64_t, int, int, int, int, int, int, int64_t, int64_t, int64_t, int,
                          hipStream_t);
@@ -540,10 +540,43 @@ int nsa_sel_scores(const void *Q, const void *K_cmp, float *p_grp, int B, int S,
         NSA_CHECK_ARG(ok, "sel_scores: MFMA route needs bf16/f16, Dk in {64,128}, h <= 16, l = 2d, l' = 4d and 16-byte aligned rows "
                           "(pass variant 1 for the generic route)");
         return launch_sel_scores_mfma(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, S_sel, d, dtype, scale, causal_skip,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, nullptr, nullptr);
     }
     return launch_sel_scores(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel,
                              dtype, scale, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// scores + top-n ranges of every row (prefill): on the 32x32x16 scorer route the selection of a query tile runs inside the scorer launch,
+// everywhere else the scorer and the select kernel are launched back to back -- the same ranges bit for bit either way
+int nsa_sel_scores_select(const void *Q, const void *K_cmp, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp, int64_t csb, int64_t csg,
+                          int64_t css, const int32_t *csc_ptr, const int32_t *csc_rows, const float *csc_vals, int S_sel, int l, int d,
+                          int l_sel, int causal_skip, int dtype, float scale, int t0, int n_top, int force_init, int force_local, int mode,
+                          int S_total, int32_t *ranges_out, int out_width, void *workspace, size_t workspace_bytes, void *stream) {
+    NSA_CHECK_ARG(dtype_ok(dtype), "sel_scores_select: unknown dtype %d", dtype);
+    NSA_CHECK_ARG(B >= 0 && S >= 0 && G >= 1 && h >= 1 && out_width >= 0, "sel_scores_select: bad sizes");
+    const int64_t R = (int64_t)B * S * G;
+    if (R == 0 || out_width == 0) return NSA_OK;
+    NSA_CHECK_ARG(p_grp && ranges_out, "sel_scores_select: null pointer");
+    if (scale <= 0.f) scale = 1.0f / sqrtf((float)Dk);
+    const int route = scores_route(B, S, G, h, Dk, S_cmp, S_sel, l, d, l_sel, dtype, 0);
+    const bool mfma_ok = route == 2 && S_cmp >= 1 && S_sel > 0 && csb % 8 == 0 && csg % 8 == 0 && css % 8 == 0 && ((uintptr_t)Q % 16 == 0) &&
+                         ((uintptr_t)K_cmp % 16 == 0) && (int64_t)B * G <= 65535;
+    if (mfma_ok) {
+        SelectParams SP{};
+        SP.p_grp = p_grp; SP.t_rows = nullptr; SP.out = ranges_out; SP.R = R; SP.S = S; SP.G = G; SP.t0 = t0;
+        if (int rc = select_params_fill(&SP, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, out_width)) return rc;
+        int done = 0;
+        if (int rc = launch_sel_scores_mfma(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, S_sel, d, dtype, scale, causal_skip,
+                                            (hipStream_t)stream, &SP, &done))
+            return rc;
+        if (done) return NSA_OK;
+    } else if (int rc = nsa_sel_scores(Q, K_cmp, p_grp, B, S, G, h, Dk, S_cmp, csb, csg, css, csc_ptr, csc_rows, csc_vals, S_sel, l, d, l_sel,
+                                       causal_skip, route == 2 ? 1 : 0 /* rows the MFMA route cannot take: the generic one */, dtype, scale,
+                                       workspace, workspace_bytes, stream)) {
+        return rc;
+    }
+    return nsa_select_topn_ranges(p_grp, R, S, G, t0, nullptr, S_sel, l_sel, n_top, force_init, force_local, mode, S_total, ranges_out,
+                                  out_width, stream);
 }
 
 // ------------------------------------------------------------------------------ selection

@@ -203,14 +203,25 @@ int nsa_layer_prefill(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void
     const float scale = 1.0f / sqrtf((float)Dk);
     // selected branch: scores (blocks no selector can read at row t are skipped) -> top-n + attention
     const bool aligned = ((uintptr_t)kv->K_cmp % 16 == 0) && kcb % 8 == 0 && kcg % 8 == 0 && Dk % 8 == 0;
-    if (int rc = nsa_sel_scores(Q, kv->K_cmp, p_grp, B, S, G, h, Dk, n_cmp, kcb, kcg, Dk, csc_ptr, csc_rows, csc_vals, S_sel, L->l, L->d,
-                                L->l_sel, 2 /* skipped blocks stay unwritten: only the selector below reads p_grp */, aligned ? 0 : 1, dt, scale, ws + W.sc,
-                                W.sc_bytes, stream))
-        return rc;
-    if (int rc = nsa_sel_select_attn_fwd(p_grp, 0, nullptr, S_sel, L->l_sel, L->n_sel, 1, 2, selector, S, ranges_out, out_width, Q, kv->K_sel,
-                                         kv->V_sel, Osel, nullptr, B, S, G, h, Dk, Dv, S, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale, ws + W.att,
-                                         W.att_bytes, stream))
-        return rc;
+    if (aligned && n_cmp >= 1 && tuning(TUNE_SEL_FUSE) <= 0) {
+        // scores + top-n in one call (round 4: on the 32x32x16 scorer's route one LAUNCH, the selection in the scorer's epilogue), then the attention
+        if (int rc = nsa_sel_scores_select(Q, kv->K_cmp, p_grp, B, S, G, h, Dk, n_cmp, kcb, kcg, Dk, csc_ptr, csc_rows, csc_vals, S_sel, L->l,
+                                           L->d, L->l_sel, 2 /* skipped blocks stay unwritten: only the selector reads p_grp */, dt, scale, 0,
+                                           L->n_sel, 1, 2, selector, S, ranges_out, out_width, ws + W.sc, W.sc_bytes, stream))
+            return rc;
+        if (int rc = nsa_sel_attn_fwd(Q, kv->K_sel, kv->V_sel, ranges_out, Osel, nullptr, B, S, G, h, Dk, Dv, S, out_width, ksb, ksg, Dk, vsb, vsg,
+                                      Dv, dt, scale, 0, ws + W.att, W.att_bytes, stream))
+            return rc;
+    } else {
+        if (int rc = nsa_sel_scores(Q, kv->K_cmp, p_grp, B, S, G, h, Dk, n_cmp, kcb, kcg, Dk, csc_ptr, csc_rows, csc_vals, S_sel, L->l, L->d,
+                                    L->l_sel, 2 /* skipped blocks stay unwritten: only the selector below reads p_grp */, aligned ? 0 : 1, dt, scale,
+                                    ws + W.sc, W.sc_bytes, stream))
+            return rc;
+        if (int rc = nsa_sel_select_attn_fwd(p_grp, 0, nullptr, S_sel, L->l_sel, L->n_sel, 1, 2, selector, S, ranges_out, out_width, Q, kv->K_sel,
+                                             kv->V_sel, Osel, nullptr, B, S, G, h, Dk, Dv, S, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale, ws + W.att,
+                                             W.att_bytes, stream))
+            return rc;
+    }
     // sliding and compressed branches
     if (int rc = nsa_band_attn_fwd(Q, kv->K_win, kv->V_win, Owin, nullptr, B, S, G, h, Dk, Dv, S, ksb, ksg, Dk, vsb, vsg, Dv, 0, 0, 1, 0, L->w,
                                    dt, scale, 0, ws + W.band, W.band_bytes, stream))

@@ -21,6 +21,7 @@
 // second sweep stops at the last selection block any query of the workgroup may select
 // ((j+1) l' <= t+1); blocks beyond are never read by the selector (masked to -inf there).
 #include "sel_scores_mfma.hpp"
+#include "sel_select_row.hpp"
 
 namespace nsa {
 
@@ -373,9 +374,12 @@ static int launch_scores_t(const ScoresMfmaParams &P, hipStream_t st) {
     return NSA_OK;
 }
 
+// sel / sel_done: the caller wants the top-n ranges of every row too; *sel_done says whether this launch produced them (the 32x32x16 form
+// selects inside the launch) or the caller has to run the select kernel behind it
 int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, int S, int G, int h, int Dk, int S_cmp,
                            int64_t csb, int64_t csg, int64_t css, int S_sel, int d_stride, int dtype, float scale,
-                           int causal_skip, hipStream_t st) {
+                           int causal_skip, hipStream_t st, const SelectParams *sel, int *sel_done) {
+    if (sel_done) *sel_done = 0;
     NSA_CHECK_ARG(css % 8 == 0 && csb % 8 == 0 && csg % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)Kc % 16 == 0),
                   "scores_mfma: Q/K_cmp must be 16-byte aligned with strides that are multiples of 8 elements");
     NSA_CHECK_ARG((int64_t)B * G <= 65535, "scores_mfma: B*G too large for one launch");
@@ -387,7 +391,11 @@ int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, i
     ScoresMfmaParams P{Q, Kc, p_grp, B, S, G, h, S_cmp, S_sel, csb, csg, css, scale, causal_skip, d_stride,
                        (int64_t)S * G * S_sel < ((int64_t)1 << 31) ? 0 : 1};
     const int form = tuning(TUNE_SCORES_FORM);
-    if ((form < 0 || form == 2) && scores_mfma32_supported(P, Dk)) return launch_scores_mfma32(P, dtype, st);
+    if ((form < 0 || form == 2) && scores_mfma32_supported(P, Dk)) {
+        const bool fuse = sel && sel_done && tuning(TUNE_SCORES_SELECT) != 0 && scores_mfma32_select_supported(P, Dk, *sel);
+        if (fuse) *sel_done = 1;
+        return launch_scores_mfma32(P, dtype, st, fuse ? sel : nullptr);
+    }
     if (dtype == NSA_DT_BF16) return Dk == 64 ? launch_scores_t<__bf16, 64>(P, st) : launch_scores_t<__bf16, 128>(P, st);
     return Dk == 64 ? launch_scores_t<_Float16, 64>(P, st) : launch_scores_t<_Float16, 128>(P, st);
 }

@@ -19,6 +19,10 @@ struct ScoresMfmaParams {
 
 // h = 6, D = 64, 32-bit output offsets: the 32x32x16 form (sel_scores_mfma32.hip)
 bool scores_mfma32_supported(const ScoresMfmaParams &P, int Dk);
-int launch_scores_mfma32(const ScoresMfmaParams &P, int dtype, hipStream_t st);
+// sel != null: the workgroup also selects the ranges of its 64 query rows, right behind its second sweep (the scores it reads back are
+// the ones it has just written: L2 hits), so the step needs no select launch; needs S_sel <= 1024 and at most 64 ranges per row
+struct SelectParams;
+bool scores_mfma32_select_supported(const ScoresMfmaParams &P, int Dk, const SelectParams &SP);
+int launch_scores_mfma32(const ScoresMfmaParams &P, int dtype, hipStream_t st, const SelectParams *sel = nullptr);
 
 }  // namespace nsa

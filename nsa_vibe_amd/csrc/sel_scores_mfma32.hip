@@ -28,6 +28,7 @@
 // Ablation switches (timing only, results meaningless; tools/ablate_scorer.sh): SC32_KSTEPS=n keeps n of the 4 k-steps, SC32_NOEXP replaces
 // v_exp_f32 by a multiply, SC32_NOSYNC drops staging and barriers, SC32_SWEEP1 stops after the first sweep.
 #include "sel_scores_mfma.hpp"
+#include "sel_select_row.hpp"
 #ifdef SC32_NOEXP  // ablation: a full-rate VALU op in place of v_exp_f32
 #define SC32_EXP(x) ((x) * 0.001f)
 #else
@@ -56,8 +57,12 @@ struct Mfma32<_Float16> {
 
 // Lane layout of one 32x32x16 MFMA (tools/ubench/probe_lanes.hip): A row and B column = lane & 31, both with k = 8 (lane >> 5) + e;
 // acc[i] of a lane = C[8 (i >> 2) + 4 (lane >> 5) + (i & 3)][lane & 31].
-template <typename T>
-__global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams P) {
+// SEL (round 4): the wave also runs the top-n selection of its 16 query rows (select_topn_row_auto: the select kernel's own row function, so
+// the ranges are those of the separate launch bit for bit) right after its second sweep.  The scores it reads are the ones it has just stored
+// (wave-private rows; its stores drained first): L2 hits instead of the 4.3 GB HBM read of a select launch at 64k x 16, and the selector's
+// scalar chains run beside the other waves' matrix / vector work -- this kernel leaves the CU's scalar unit idle, the select kernel is bound by it.
+template <typename T, bool SEL>
+__global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams P, SelectParams SP) {
     using M = Mfma32<T>;
     using x8 = typename M::x8;
     constexpr int D = 64, HC = 6;
@@ -372,6 +377,37 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
         __syncthreads();
 #endif
     }
+    if constexpr (SEL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's score stores have reached L2
+        int *sc = (int *)&stn[wave][0][0];                 // run-extraction scratch (the stencil ring is dead)
+        // the wave's 16 rows one after the other, the next row's scores fetched while this one is selected (a row is a chain of dependent
+        // steps behind its loads: without the overlap the epilogue held the workgroup's registers and LDS for 16 L2 round trips more)
+        const int nq = min(QPW, P.S - tw);
+        const int sh = SP.l_sel_shift;
+        auto fetch = [&](int qi, float (&dst)[16]) {
+            const int t = SP.t0 + tw + min(qi, nq - 1);
+            const int nvalid = min(SP.S_sel, sh >= 0 ? (t + 1) >> sh : (t + 1) / SP.l_sel);
+            const int jmax = max(nvalid - 1, 0);
+            const float *pr = SP.p_grp + (((int64_t)b * P.S + tw + min(qi, nq - 1)) * P.G + g) * (int64_t)SP.S_sel;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c] = pr[min(lane + 64 * c, jmax)];
+        };
+        auto select = [&](int qi, const float (&src)[16]) {
+            const int t = uniform(tw + qi);
+            const int64_t row = ((int64_t)b * P.S + t) * P.G + g;
+            select_topn_row_auto<16>(SP, SP.p_grp + row * (int64_t)SP.S_sel, SP.t0 + t, SP.out + row * (int64_t)SP.W * 2, sc, src);
+        };
+        float va[16], vb[16];
+        if (nq > 0) fetch(0, va);
+        for (int qi = 0; qi < nq; qi += 2) {
+            fetch(qi + 1, vb);
+            select(qi, va);
+            if (qi + 1 < nq) {
+                fetch(qi + 2, va);
+                select(qi + 1, vb);
+            }
+        }
+    }
 }
 
 // ---- host -----------------------------------------------------------------------------------
@@ -380,10 +416,20 @@ bool scores_mfma32_supported(const ScoresMfmaParams &P, int Dk) {
     return P.h == 6 && Dk == 64 && !P.big_out && (int64_t)P.S * P.G * P.S_sel * 4 < ((int64_t)1 << 32);
 }
 
-int launch_scores_mfma32(const ScoresMfmaParams &P, int dtype, hipStream_t st) {
+bool scores_mfma32_select_supported(const ScoresMfmaParams &P, int Dk, const SelectParams &SP) {
+    return scores_mfma32_supported(P, Dk) && P.S_sel <= 1024 && SP.W >= 1 && SP.W <= 64 && SP.t_rows == nullptr;
+}
+
+int launch_scores_mfma32(const ScoresMfmaParams &P, int dtype, hipStream_t st, const SelectParams *sel) {
     dim3 grid((unsigned)((P.S + 63) / 64), (unsigned)(P.B * P.G));
-    if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((scores_mfma32_kernel<__bf16>), grid, dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((scores_mfma32_kernel<_Float16>), grid, dim3(256), 0, st, P);
+    if (sel) {
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((scores_mfma32_kernel<__bf16, true>), grid, dim3(256), 0, st, P, *sel);
+        else hipLaunchKernelGGL((scores_mfma32_kernel<_Float16, true>), grid, dim3(256), 0, st, P, *sel);
+    } else {
+        const SelectParams none{};
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((scores_mfma32_kernel<__bf16, false>), grid, dim3(256), 0, st, P, none);
+        else hipLaunchKernelGGL((scores_mfma32_kernel<_Float16, false>), grid, dim3(256), 0, st, P, none);
+    }
     NSA_LAUNCH_CHECK("scores_mfma32");
     return NSA_OK;
 }

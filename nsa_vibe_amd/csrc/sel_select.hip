@@ -30,31 +30,7 @@ __global__ __launch_bounds__(256) void select_topn_kernel(SelectParams P) {
     else if (P.R < ((int64_t)1 << 31)) t = P.t0 + (int)(((unsigned)row / (unsigned)P.G) % (unsigned)P.S);
     else t = P.t0 + (int)((row / P.G) % P.S);
     t = uniform(t);
-    // candidates per lane for THIS row: only blocks up to the current one can be valid or forced, so an early row of a long sequence runs the
-    // instantiation of a short one (the per-lane sort, the key transform and the pick masks scale with the slot count: at 64k the average row
-    // needs 10.7 of the 16 slots' worth of work)
-    const float *p = P.p_grp + row * (int64_t)P.S_sel;
-    int32_t *out = P.out + row * (int64_t)P.W * 2;
-    int *sc = scr[threadIdx.x >> 6];
-    const int sh = P.l_sel_shift;
-    const int cblk = max(sh >= 0 ? t >> sh : t / P.l_sel, 0);
-    const int need = (min(cblk + 1, P.S_sel) + 63) >> 6;  // slots that hold a block <= cblk
-    if constexpr (CAND >= 2) {
-        if (need <= 1) return select_topn_row<1>(P, p, t, out, sc);
-    }
-    if constexpr (CAND >= 4) {
-        if (need <= 2) return select_topn_row<2>(P, p, t, out, sc);
-    }
-    if constexpr (CAND >= 8) {
-        if (need <= 4) return select_topn_row<4>(P, p, t, out, sc);
-    }
-    if constexpr (CAND >= 16) {
-        if (need <= 8) return select_topn_row<8>(P, p, t, out, sc);
-    }
-    if constexpr (CAND >= 32) {
-        if (need <= 16) return select_topn_row<16>(P, p, t, out, sc);
-    }
-    select_topn_row<CAND>(P, p, t, out, sc);
+    select_topn_row_auto<CAND>(P, P.p_grp + row * (int64_t)P.S_sel, t, P.out + row * (int64_t)P.W * 2, scr[threadIdx.x >> 6]);
 }
 
 // ---- v2 converter alone: one thread per row -------------------------------------------------

@@ -66,8 +66,10 @@ __device__ __forceinline__ void extract_runs_lanes(const unsigned long long (&wd
 // blk_list (LDS, >= n_top + 3 ints, wave private until the caller publishes it) / nblk: the selected blocks themselves, ascending, and
 // their count -- what a consumer that walks blocks (the fused decode step) needs, before and independent of the run extraction.
 template <int CAND, bool SORT_ALL = false>
+// pre (optional): the row's raw scores already in registers, pre[c] = p[min(lane + 64 c, max(nvalid - 1, 0))] -- a caller that selects
+// several rows one after the other fetches the next row's while this one is processed (the scorer's epilogue)
 __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, const float *p, const int t, int &my_s, int &my_e,
-                                                     int *scr = nullptr, int *blk_list = nullptr, int *nblk = nullptr) {
+                                                     int *scr = nullptr, int *blk_list = nullptr, int *nblk = nullptr, const float *pre = nullptr) {
     const int lane = lane_id();
     const int l_sel = P.l_sel, S_sel = P.S_sel;
     const int sh = P.l_sel_shift;
@@ -84,7 +86,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
     const int jmax = max(nvalid_blocks - 1, 0);
     float vraw[CAND];
 #pragma unroll
-    for (int c = 0; c < CAND; ++c) vraw[c] = p[min(lane + 64 * c, jmax)];
+    for (int c = 0; c < CAND; ++c) vraw[c] = pre ? pre[c] : p[min(lane + 64 * c, jmax)];
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
         const int j = lane + 64 * c;
@@ -336,10 +338,11 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
 
 // same, storing the row's [W,2] ranges
 template <int CAND>
-__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out, int *scr = nullptr) {
+__device__ __forceinline__ void select_topn_row(const SelectParams &P, const float *p, const int t, int32_t *out, int *scr = nullptr,
+                                                const float *pre = nullptr) {
     const int lane = lane_id();
     int my_s, my_e;
-    select_topn_row_regs<CAND, (CAND <= 32)>(P, p, t, my_s, my_e, scr);
+    select_topn_row_regs<CAND, (CAND <= 32)>(P, p, t, my_s, my_e, scr, nullptr, nullptr, pre);
     if (lane < P.W) {
         out[2 * lane] = my_s;
         out[2 * lane + 1] = my_e;
@@ -349,6 +352,33 @@ __device__ __forceinline__ void select_topn_row(const SelectParams &P, const flo
         out[2 * i] = 0;
         out[2 * i + 1] = 0;
     }
+}
+
+// one wave, one row, the instantiation picked per row: only blocks up to the current one can be valid or forced, so an early row of a long
+// sequence runs the instantiation of a short one (the per-lane sort, the key transform and the pick masks scale with the slot count: at 64k
+// the average row needs 10.7 of the 16 slots' worth of work).  t must be wave uniform.
+template <int CAND>
+__device__ __forceinline__ void select_topn_row_auto(const SelectParams &P, const float *p, const int t, int32_t *out, int *sc,
+                                                     const float *pre = nullptr) {
+    const int sh = P.l_sel_shift;
+    const int cblk = max(sh >= 0 ? t >> sh : t / P.l_sel, 0);
+    const int need = (min(cblk + 1, P.S_sel) + 63) >> 6;  // slots that hold a block <= cblk
+    if constexpr (CAND >= 2) {
+        if (need <= 1) return select_topn_row<1>(P, p, t, out, sc, pre);
+    }
+    if constexpr (CAND >= 4) {
+        if (need <= 2) return select_topn_row<2>(P, p, t, out, sc, pre);
+    }
+    if constexpr (CAND >= 8) {
+        if (need <= 4) return select_topn_row<4>(P, p, t, out, sc, pre);
+    }
+    if constexpr (CAND >= 16) {
+        if (need <= 8) return select_topn_row<8>(P, p, t, out, sc, pre);
+    }
+    if constexpr (CAND >= 32) {
+        if (need <= 16) return select_topn_row<16>(P, p, t, out, sc, pre);
+    }
+    select_topn_row<CAND>(P, p, t, out, sc, pre);
 }
 
 // host: SelectParams of the sequential selector (decode / per-row prefill), see sel_select.hip

@@ -148,6 +148,44 @@ def selection_scores(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, 
     return p_grp
 
 
+def selection_scores_select(Q_all: torch.Tensor, K_cmp: torch.Tensor, meta: BlockMeta, n_top: int, *, mode: str = "batched", t0: int = 0,
+                            scale: Optional[float] = None, force_init: bool = True, force_local: int = 2, leave_skipped: bool = True):
+    """Prefill (inference): group scores AND the top-n ranges of every row in ONE native call (nsa_sel_scores_select) -- on the MFMA scorer's
+    default route (h = 6, Dk = 64, default block geometry, bf16 / f16, up to 1024 selection blocks) in one LAUNCH: a workgroup selects the
+    ranges of its 64 query rows right behind its second sweep, reading its scores back out of L2.  Q [B,S,G,h,Dk], K_cmp [B,G,S_cmp,Dk] ->
+    (p_grp [B,S,G,S_sel] fp32 with blocks no selector can read skipped, ranges [B,S,G,W,2] int32).  mode "batched" =
+    select_topn_ranges_batched (nsa/core/selection_scorer.py:255-362), "sequential" = select_topn_ranges at token t0 + s (:124-249).
+    ranges are bit-identical to selection_scores(..., causal_skip=True) followed by select_topn_ranges_batched / _rows."""
+    dev = _need_gpu(Q_all, K_cmp)
+    B, S, G, h, Dk = Q_all.shape
+    S_cmp, S_sel = K_cmp.shape[2], meta.S_sel
+    if mode == "batched":
+        md, W = _lib.NSA_SEL_BATCHED, batched_ranges_width(S_sel, meta.l_sel, n_top, S, force_init, force_local)
+    elif mode == "sequential":
+        md, W = _lib.NSA_SEL_SEQUENTIAL, n_top
+    else:
+        raise ValueError("mode must be 'batched' or 'sequential'")
+    Q_all = Q_all.contiguous()
+    K_cmp, sb, sg, ss = _kc_strides(K_cmp)
+    p_grp = torch.empty((B, S, G, S_sel), dtype=torch.float32, device=dev)
+    ranges = torch.empty((B, S, G, W, 2), dtype=torch.int32, device=dev)
+    if p_grp.numel() == 0 or W == 0:
+        return p_grp, ranges
+    L = _lib.lib()
+    dt = _DT[Q_all.dtype]
+    geo = (int(meta.l), int(meta.d), int(meta.l_sel))
+    nbytes = max(L.nsa_sel_scores_workspace(B, S, G, h, Dk, S_cmp, S_sel, *geo, dt, 0), L.nsa_sel_scores_workspace(B, S, G, h, Dk, S_cmp, S_sel, *geo, dt, 1))
+    ws = workspace(dev, nbytes, "scores")
+    cptr, crows, cvals = meta.device_csc(dev)
+    rc = L.nsa_sel_scores_select(Q_all.data_ptr(), K_cmp.data_ptr(), p_grp.data_ptr(), B, S, G, h, Dk, S_cmp, sb, sg, ss,
+                                 cptr.data_ptr(), crows.data_ptr(), cvals.data_ptr(), S_sel, *geo, 2 if leave_skipped else 1, dt,
+                                 float(scale) if scale else 0.0, int(t0), int(n_top), int(bool(force_init)), int(force_local), md, S,
+                                 ranges.data_ptr(), W, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                 _stream(dev))
+    _lib.check(rc, "nsa_sel_scores_select")
+    return p_grp, ranges
+
+
 def _select(p_rows: torch.Tensor, R: int, S: int, G: int, t0: int, t_rows, meta: BlockMeta, n_top: int, force_init,
             force_local, mode: int, S_total: int, width: int) -> torch.Tensor:
     dev = p_rows.device

@@ -949,3 +949,47 @@ def test_decode_step_team_that_never_assembles(nv, tune, S_ctx, B):
                 assert torch.equal(O1, O2), (nw, ns, spin)
                 if nw == 16:
                     assert torch.equal(O0, O1), (nw, ns, spin)
+
+
+@pytest.mark.parametrize("S,B,mode", [(4096, 3, "batched"), (4096, 2, "sequential"), (700, 2, "batched"), (16384, 2, "batched"), (65536, 1, "batched"),
+                                      (65536, 1, "sequential"), (4100, 1, "batched")])
+def test_scores_and_select_in_one_launch_equals_the_two_launches(nv, orc, tune, S, B, mode):
+    """nsa_sel_scores_select (round 4): on the 32x32x16 scorer's route the top-n selection of a query tile runs inside the scorer launch -- the
+    select kernel's own row function on the scores the workgroup has just written -- so the ranges must be those of selection_scores ->
+    select_topn_ranges_batched / _rows bit for bit, and the scores the same bits wherever a selector reads them; SCORES_SELECT = 0 (two
+    launches behind the same entry point) as well.  Reference: nsa/core/nsa_attention.py:1088-1108, 1566-1576."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(S + B)
+    G, h, D, n = 2, 6, 64, 16
+    meta = nv.build_block_meta(S, 32, 16, 64, n, 512)
+    Q = torch.randn(B, S, G, h, D, device="cuda", generator=g).bfloat16()
+    Kc = torch.randn(B, G, meta.S_cmp, D, device="cuda", generator=g).bfloat16()
+    p0 = nv.selection_scores(Q, Kc, meta, causal_skip=True)
+    r0 = nv.select_topn_ranges_batched(p0, meta, n, S) if mode == "batched" else nv.select_topn_ranges_rows(p0, meta, n, 0)
+    for sw in (-1, 0):
+        tune("SCORES_SELECT", sw)
+        p1, r1 = nv.selection_scores_select(Q, Kc, meta, n, mode=mode)
+        p2, r2 = nv.selection_scores_select(Q, Kc, meta, n, mode=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1) and torch.equal(r1, r2), (sw, mode)
+        # scores: equal where a selector may read them (row t: blocks j with (j + 1) * 64 <= t + 1)
+        t = torch.arange(S, device="cuda")[None, :, None, None]
+        j = torch.arange(meta.S_sel, device="cuda")[None, None, None, :]
+        ok = (j + 1) * 64 <= t + 1
+        assert torch.equal(torch.where(ok, p0, 0), torch.where(ok, p1, 0)), sw
+
+
+def test_scores_and_select_falls_back_to_two_launches_off_the_mfma32_route(nv, tune):
+    """h = 4 (the 16x16 scorer) and fp32 inputs (the generic scorer): nsa_sel_scores_select runs scorer + select kernel back to back, same results"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    for h, dtype in ((4, torch.bfloat16), (6, torch.float32)):
+        B, S, G, D, n = 2, 1500, 2, 64, 16
+        meta = nv.build_block_meta(S, 32, 16, 64, n, 512)
+        Q = torch.randn(B, S, G, h, D, device="cuda", generator=g).to(dtype)
+        Kc = torch.randn(B, G, meta.S_cmp, D, device="cuda", generator=g).to(dtype)
+        p0 = nv.selection_scores(Q, Kc, meta, causal_skip=True)
+        r0 = nv.select_topn_ranges_batched(p0, meta, n, S)
+        p1, r1 = nv.selection_scores_select(Q, Kc, meta, n)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1), (h, dtype)

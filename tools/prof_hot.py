@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Focused workloads for rocprofv3 passes (kernel trace or PMC): the hot path of bench.py at one shape, a few launches.
 
-    ... -- python3 tools/prof_hot.py prefill <S> <B> <iters> [attn|scores|select|all]     (select + attend launch / scorer / both)
+    ... -- python3 tools/prof_hot.py prefill <S> <B> <iters> [attn|scores|select|scsel|all]     (select + attend launch / scorer / both)
     ... -- python3 tools/prof_hot.py bwd <S> <B> <iters>                           (selection attention forward + backward, autograd)
     ... -- python3 tools/prof_hot.py decode  <B> <S_ctx> <iters>                   (nsa_sel_decode_step, the same cache every step: warm)
     ... -- python3 tools/prof_hot.py decode_cold <B> <S_ctx> <iters>               (the steps rotate over bench.py's independent cache sets: cold)
@@ -29,6 +29,8 @@ if mode == "prefill":
             p = nv.selection_scores(Q, Kc, meta, causal_skip=True, leave_skipped=True)
         if stage in ("attn", "all"):
             nv.select_and_attend(p, Q, K, V, meta, bench.N_SEL, mode="batched")
+        if stage == "scsel":  # scores + top-n in one launch (nsa_sel_scores_select)
+            nv.selection_scores_select(Q, Kc, meta, bench.N_SEL, mode="batched")
         if stage == "select":
             nv.select_topn_ranges_batched(p, meta, bench.N_SEL, S)
     torch.cuda.synchronize()
