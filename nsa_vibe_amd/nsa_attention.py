@@ -37,7 +37,23 @@ from .selection_attention import (
     selection_attention_hip,
     selection_decode_step,
 )
-from .selection_scorer import _DT, _stream, select_topn_ranges_batched, select_topn_ranges_rows, selection_scores, workspace
+from .selection_scorer import (_DT, _stream, select_topn_ranges_batched, select_topn_ranges_rows, selection_scores, selection_scores_select,
+                               workspace)
+
+_ORIG_SELECTORS = (select_topn_ranges_batched, select_topn_ranges_rows)
+
+
+def _scores_and_ranges(Q, K_cmp, meta, n_sel, selector, S, scale):
+    """group scores -> top-n ranges of every row.  One native call (nsa_sel_scores_select: on the MFMA scorer's route one launch) -- unless
+    somebody has replaced the selector functions of THIS module (the reference's tests patch these names on nsa.core.nsa_attention,
+    nsa/tests/test_causality_asserts.py:54-56): a patched selector must be the one that runs."""
+    g = globals()
+    if (g["select_topn_ranges_batched"], g["select_topn_ranges_rows"]) == _ORIG_SELECTORS:
+        return selection_scores_select(Q, K_cmp, meta, n_sel, mode=selector, scale=scale)[1]
+    p_grp = selection_scores(Q, K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
+    if selector == "batched":
+        return g["select_topn_ranges_batched"](p_grp, meta, n_sel, S, True, 2)
+    return g["select_topn_ranges_rows"](p_grp, meta, n_sel, 0, True, 2)
 
 
 def apply_rope(x: torch.Tensor, pos: torch.Tensor, base: float = 10000.0, scale: float = 1.0) -> torch.Tensor:
@@ -427,11 +443,7 @@ class NSAAttention(nn.Module):
         scale = 1.0 / math.sqrt(self.d_k)
         Qc = Q.contiguous()
         # ---- selected branch (HIP): scores -> ranges -> attention
-        p_grp = selection_scores(Qc, kv.K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
-        if self.selector == "batched":
-            ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
-        else:
-            ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+        ranges = _scores_and_ranges(Qc, kv.K_cmp, meta, self.n_sel, self.selector, S, scale)
         if self._force_parity:  # reference gather routes: batched -> first gathered key, sequential -> _sdpa_over_ranges
             parity = selection_attention_first_key_parity if self.selector == "batched" else selection_attention_head_causal_parity
             O_sel = parity(Qc, kv.K_sel, kv.V_sel, ranges)
@@ -489,11 +501,7 @@ class NSAAttention(nn.Module):
         meta = kv.ensure_meta(S)
         scale = 1.0 / math.sqrt(self.d_k)
         with torch.no_grad():  # the selection itself is not differentiable (top-n indices)
-            p_grp = selection_scores(Q.detach(), kv.K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
-            if self.selector == "batched":
-                ranges = select_topn_ranges_batched(p_grp, meta, self.n_sel, S, True, 2)
-            else:
-                ranges = select_topn_ranges_rows(p_grp, meta, self.n_sel, 0, True, 2)
+            ranges = _scores_and_ranges(Q.detach(), kv.K_cmp, meta, self.n_sel, self.selector, S, scale)
         self._last_ranges = ranges
         O_sel = selection_attention_hip(Q, K_sel, V_sel, ranges, scale=scale)
         O_cmp = batched_causal_attention_compressed(Q, K_cmp, V_cmp, self.l, self.d, scale=scale)
