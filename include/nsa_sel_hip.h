@@ -330,8 +330,8 @@ NSA_API int nsa_select_topn_ranges(const float *p_grp, int64_t R, int S, int G, 
  * nsa_select_topn_ranges (rows in the [B,S,G] order of Q, token of row (b,s,g) = t0 + s).  Replaces compute_pcmp_all ->
  * map_pcmp_to_pslc_batched -> sum(dim=3) -> select_topn_ranges[_batched] (nsa/core/nsa_attention.py:1088-1108, 1566-1576;
  * nsa/core/selection_scorer.py:42-61, 89-116, 124-249, 255-362).  Where the 32x32x16 MFMA scorer applies (h = 6, Dk = 64, default block
- * geometry, bf16 / f16, S_sel <= 1024) a workgroup selects the ranges of its 64 query rows right behind its second sweep, with the select
- * kernel's own row function: ONE launch, the scores are read back out of L2 (no HBM read of p_grp), the selector's scalar work runs beside
+ * geometry, bf16 / f16, S_sel <= 1024) and the context is long enough for it to pay (S_cmp >= 3072; tuning switch "SCORES_SELECT") a workgroup
+ * selects the ranges of its 64 query rows right behind its second sweep, with the select kernel's own row function: ONE launch, the scores are read back out of L2 (no HBM read of p_grp), the selector's scalar work runs beside
  * the scorer's matrix / vector work.  Everywhere else the scorer and the select kernel are launched back to back.  p_grp is still written
  * (same contract as nsa_sel_scores with the given causal_skip); ranges_out is bit-identical to the two separate calls either way.
  * workspace: the larger of nsa_sel_scores_workspace(..., variant 0) and (..., variant 1) bytes (rows that are not 16-byte aligned take the

@@ -56,7 +56,7 @@ enum Tune {
     TUNE_DECODE_WIDE,       // NSA_HIP_DECODE_WIDE: one-launch decode step, a long row in ONE workgroup: 1 = four chunks per wave with the later chunks' logits in LDS (exact), 2 = the one-pass form (eight chunks per wave, scores within 2 ulp), wherever the row fits; -1 = only where a team of workgroups would not fit the chip; 0 = never
     TUNE_SEL_KSPLIT_T1,     // NSA_HIP_SEL_KSPLIT_T1 / _T2: key-split attention, rows from this position on (position = row + S_kv - S) are split 2-way / 4-way; -1 = 32768 / never
     TUNE_SEL_KSPLIT_T2,
-    TUNE_SCORES_SELECT,     // NSA_HIP_SCORES_SELECT: nsa_sel_scores_select, 1 / -1 = the top-n selection of a query tile runs inside the scorer launch (32x32x16 form), 0 = its own launch
+    TUNE_SCORES_SELECT,     // NSA_HIP_SCORES_SELECT: nsa_sel_scores_select, 1 = the top-n selection of a query tile always runs inside the scorer launch (32x32x16 form), 0 = always its own launch, -1 = inside from 48k contexts on (S_cmp >= 3072: where it is faster)
     TUNE_COUNT
 };
 int tuning(Tune t);

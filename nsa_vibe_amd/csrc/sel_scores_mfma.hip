@@ -392,7 +392,11 @@ int launch_sel_scores_mfma(const void *Q, const void *Kc, float *p_grp, int B, i
                        (int64_t)S * G * S_sel < ((int64_t)1 << 31) ? 0 : 1};
     const int form = tuning(TUNE_SCORES_FORM);
     if ((form < 0 || form == 2) && scores_mfma32_supported(P, Dk)) {
-        const bool fuse = sel && sel_done && tuning(TUNE_SCORES_SELECT) != 0 && scores_mfma32_select_supported(P, Dk, *sel);
+        // in the launch only where it pays (same box, tools/bench_scores_select.py: 64k x 4 3,537 -> 3,433 us, 64k x 1 905 -> 890, but 32k x 2
+        // 509 -> 521, 16k x 2 161 -> 180, 4k x 8 75 -> 87): a wave's 16 rows are 16 dependent chains of ~2 us behind its sweeps, which only
+        // a long sweep (a workgroup's lifetime grows with S_cmp) and many workgroups per CU hide.  TUNE_SCORES_SELECT: -1 this rule, 0 never, 1 always
+        const int mode = tuning(TUNE_SCORES_SELECT);
+        const bool fuse = sel && sel_done && mode != 0 && (mode > 0 || S_cmp >= 3072) && scores_mfma32_select_supported(P, Dk, *sel);
         if (fuse) *sel_done = 1;
         return launch_scores_mfma32(P, dtype, st, fuse ? sel : nullptr);
     }

@@ -966,7 +966,7 @@ def test_scores_and_select_in_one_launch_equals_the_two_launches(nv, orc, tune, 
     Kc = torch.randn(B, G, meta.S_cmp, D, device="cuda", generator=g).bfloat16()
     p0 = nv.selection_scores(Q, Kc, meta, causal_skip=True)
     r0 = nv.select_topn_ranges_batched(p0, meta, n, S) if mode == "batched" else nv.select_topn_ranges_rows(p0, meta, n, 0)
-    for sw in (-1, 0):
+    for sw in (1, 0, -1):  # in the launch / its own launch / by context length
         tune("SCORES_SELECT", sw)
         p1, r1 = nv.selection_scores_select(Q, Kc, meta, n, mode=mode)
         p2, r2 = nv.selection_scores_select(Q, Kc, meta, n, mode=mode)
