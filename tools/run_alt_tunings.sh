@@ -11,3 +11,8 @@ run NSA_HIP_SEL_ROWS=1 NSA_HIP_DECODE_UNFUSED=1 NSA_HIP_DECODE_WG=0 NSA_HIP_SCOR
 run NSA_HIP_SEL_ROWS=0 NSA_HIP_ATTN_STAGE=0 NSA_HIP_BAND_STAGE=0 NSA_HIP_ATTN_MAP=0
 run NSA_HIP_SEL_BLOCKS=2 NSA_HIP_DECODE_UNFUSED=0 NSA_HIP_ATTN_MAP=1
 run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0
+# round 4: the zoned key split on every attention shape of the suite (rows whole / in two / in four key classes by position), the selection
+# inside the scorer launch at every length, and the exact one-workgroup form of the decode step wherever a row fits it
+run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0 NSA_HIP_SEL_KSPLIT_T1=200 NSA_HIP_SEL_KSPLIT_T2=900
+run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0 NSA_HIP_SEL_KSPLIT_T1=0 NSA_HIP_SEL_KSPLIT_T2=0
+run NSA_HIP_SCORES_SELECT=1 NSA_HIP_DECODE_WIDE=1
