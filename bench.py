@@ -817,7 +817,7 @@ def main():
                 # BASELINE metric: decode tok/s at S in {4k, 16k, 64k}; every figure COLD (rotating cache sets, decode_bench); the top-level
                 # decode_roofline is the S = 65536 configuration (north_star's length) with the highest cold fraction
                 best = None
-                for Bd, Sd in ((64, 4096), (256, 4096), (64, 16384), (128, 16384), (256, 16384), (64, 65536), (128, 65536), (256, 65536), (1, 65536)):
+                for Bd, Sd in ((64, 4096), (256, 4096), (64, 16384), (128, 16384), (256, 16384), (64, 65536), (128, 65536), (256, 65536), (512, 65536), (1, 65536)):
                     d = decode_bench(nv, Bd, Sd, 30, device)
                     extra[f"decode_B{Bd}_S{Sd}"] = d
                     rl = decode_roofline(d, pmc_traffic(f"decode_cold_B{Bd}_S{Sd}"))

@@ -16,7 +16,7 @@ import nsa_vibe_amd as nv  # noqa: E402
 
 dev = torch.device("cuda", 0)
 shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [
-    (64, 4096), (256, 4096), (64, 16384), (128, 16384), (256, 16384), (64, 65536), (128, 65536), (256, 65536), (1, 65536)]
+    (64, 4096), (256, 4096), (64, 16384), (128, 16384), (256, 16384), (64, 65536), (128, 65536), (256, 65536), (512, 65536), (1, 65536)]
 print(f"{'B':>4} {'S':>6} {'sets':>4} {'cold us':>8} {'warm us':>8} {'cold GB/s':>9} {'frac':>5} {'warm frac':>9} {'tok/s cold':>11}")
 for B, S in shapes:
     d = bench.decode_bench(nv, B, S, 30, dev)
