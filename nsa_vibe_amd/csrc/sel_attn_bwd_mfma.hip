@@ -415,6 +415,9 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P,
     [[maybe_unused]] const int krowb32 = uniform((int)krowb), vrowb32 = uniform((int)vrowb);
     [[maybe_unused]] const int kstep = uniform(8 * (int)krowb), vstep = uniform(8 * (int)vrowb);
     auto issue_dma = [&](int tok0) {
+#ifdef DQ_NODMA  // ablation (timing only, results meaningless): no K / V tile fetches
+        return;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef __attribute__((address_space(3))) void lds_void;
         const int ks = uniform(tok0 * krowb32), vs = uniform(tok0 * vrowb32);
@@ -510,6 +513,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_rows_kernel(SelAttnBwdParams P,
             km >>= 4 * q;  // bit 16u + j = key 16u + 4q + j of the tile
         }
 
+#ifdef DQ_NOCOMPUTE  // ablation (timing only): tile walk and fetches without the products
+        cur = nxt;
+        continue;
+#endif
         f32x4 sacc[2], pacc[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
