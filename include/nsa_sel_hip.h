@@ -97,6 +97,10 @@ NSA_API int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes);
  *           no workspace the call falls back to the forms that need none.
  * ------------------------------------------------------------------------------------- */
 NSA_API size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype);
+/* the same for query rows that are the LAST S positions of a longer context (S_kv > S: a chunk of a chunked prefill): the key-split form splits
+ * rows by their position S_kv - S + row, so it may need records where the S_kv = S query above sees none.  A launch whose workspace is too
+ * small for the split form runs the unsplit walk (same results within one ulp of the output dtype, slower at long contexts). */
+NSA_API size_t nsa_sel_attn_fwd_workspace_kv(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int dtype);
 NSA_API int nsa_sel_attn_fwd(const void *Q, const void *K, const void *V, const int32_t *ranges, void *O,
                      float *lse, int B, int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges,
                      int64_t k_stride_b, int64_t k_stride_g, int64_t k_stride_s, int64_t v_stride_b,

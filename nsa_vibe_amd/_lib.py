@@ -49,6 +49,7 @@ SIGNATURES = {
     "nsa_hip_set_tuning": (_i, [C.c_char_p, _i]),
     "nsa_hip_get_tuning": (_i, [C.c_char_p, C.POINTER(_i)]),
     "nsa_sel_attn_fwd_workspace": (_sz, [_i] * 8),
+    "nsa_sel_attn_fwd_workspace_kv": (_sz, [_i] * 9),
     "nsa_sel_attn_fwd": (_i, [_vp] * 6 + [_i] * 8 + [_i64] * 6 + [_i, _f, _i, _vp, _sz, _vp]),
     "nsa_sel_attn_first_key_parity": (_i, [_vp] * 3 + [_i] * 7 + [_i64] * 3 + [_i, _vp]),
     "nsa_sel_attn_head_causal_parity": (_i, [_vp] * 5 + [_i] * 8 + [_i64] * 6 + [_i, _f, _vp]),

@@ -138,12 +138,16 @@ int nsa_hip_device_check(int dev, int *cu_count, size_t *hbm_bytes) {
 }
 
 // ------------------------------------------------------------------------------ attention
-size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype) {
+size_t nsa_sel_attn_fwd_workspace_kv(int B, int S, int G, int h, int Dk, int Dv, int S_kv, int n_ranges, int dtype) {
     if (!sel_attn_mfma_supported(dtype, h, Dk, Dv)) return 0;
     const size_t split_kv = sel_attn_mfma_workspace((int64_t)B * S * G, h, Dv, nullptr);
-    // key-split form of the block kernel (long contexts, several sequences): sized for the prefill case S_kv = S
-    const size_t key_split = sel_attn_ksplit_workspace(dtype, h, Dk, Dv, S, S, n_ranges, (int64_t)B * S * G);
+    // key-split form of the block kernel (long contexts): its zones follow the rows' positions S_kv - S + row
+    const size_t key_split = sel_attn_ksplit_workspace(dtype, h, Dk, Dv, S, S_kv > S ? S_kv : S, n_ranges, (int64_t)B * S * G);
     return split_kv > key_split ? split_kv : key_split;
+}
+
+size_t nsa_sel_attn_fwd_workspace(int B, int S, int G, int h, int Dk, int Dv, int n_ranges, int dtype) {
+    return nsa_sel_attn_fwd_workspace_kv(B, S, G, h, Dk, Dv, S, n_ranges, dtype);  // the prefill case S_kv = S
 }
 
 }  // extern "C"

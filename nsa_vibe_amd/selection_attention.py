@@ -62,7 +62,7 @@ def _fwd(Q, K, V, ranges, scale, variant, want_lse):
         return O, lse, (Qc, Kc, Vc, rg)
     L = _lib.lib()
     dt = _DT[Q.dtype]
-    ws = workspace(dev, L.nsa_sel_attn_fwd_workspace(B, S, G, h, Dk, Dv, n, dt), "attn")
+    ws = workspace(dev, L.nsa_sel_attn_fwd_workspace_kv(B, S, G, h, Dk, Dv, S_kv, n, dt), "attn")
     rc = L.nsa_sel_attn_fwd(Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), rg.data_ptr(), O.data_ptr(),
                             lse.data_ptr() if lse is not None else None, B, S, G, h, Dk, Dv, S_kv, n,
                             Kc.stride(0), Kc.stride(1), Kc.stride(2), Vc.stride(0), Vc.stride(1), Vc.stride(2),
@@ -227,7 +227,7 @@ def select_and_attend(p_grp: torch.Tensor, Q: torch.Tensor, K: torch.Tensor, V: 
         return (ranges, O, lse) if return_lse else (ranges, O)
     L = _lib.lib()
     dt = _DT[Q.dtype]
-    ws = workspace(dev, L.nsa_sel_attn_fwd_workspace(B, S, G, h, Dk, Dv, W, dt), "attn")
+    ws = workspace(dev, L.nsa_sel_attn_fwd_workspace_kv(B, S, G, h, Dk, Dv, S_kv, W, dt), "attn")
     rc = L.nsa_sel_select_attn_fwd(pg.data_ptr(), int(t0), None, S_sel, int(meta.l_sel), int(n_top), int(bool(force_init)), int(force_local),
                                    md, S, ranges.data_ptr(), W, Qc.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), O.data_ptr(),
                                    lse.data_ptr() if lse is not None else None, B, S, G, h, Dk, Dv, S_kv,

@@ -781,6 +781,10 @@ def test_key_split_rows_at_the_end_of_a_longer_context(nv, orc, tune):
     assert (plain.float() - out.float()).abs().max().item() <= 1.6e-2
     want = orc.sel_attention_masked(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), rg.cpu().numpy())
     assert np.abs(out.float().cpu().numpy() - want).max() <= 1e-2
+    # the zones really follow the positions: rows below position 2600 (row < 112; workgroups hold 32 rows: boundary row 128) are walked whole --
+    # the plain walk's bits -- while the split rows went through f16 records and differ from it in some last bits
+    assert torch.equal(out[:, :96], plain[:, :96])
+    assert not torch.equal(out[:, 128:], plain[:, 128:])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
