@@ -40,17 +40,17 @@ from .selection_attention import (
 from .selection_scorer import (_DT, _stream, select_topn_ranges_batched, select_topn_ranges_rows, selection_scores, selection_scores_select,
                                workspace)
 
-_ORIG_SELECTORS = (select_topn_ranges_batched, select_topn_ranges_rows)
+_ORIG_SELECTORS = (select_topn_ranges_batched, select_topn_ranges_rows, selection_scores)
 
 
 def _scores_and_ranges(Q, K_cmp, meta, n_sel, selector, S, scale):
     """group scores -> top-n ranges of every row.  One native call (nsa_sel_scores_select: on the MFMA scorer's route one launch) -- unless
-    somebody has replaced the selector functions of THIS module (the reference's tests patch these names on nsa.core.nsa_attention,
-    nsa/tests/test_causality_asserts.py:54-56): a patched selector must be the one that runs."""
+    somebody has replaced the scorer / selector functions of THIS module (the reference's tests patch these names on nsa.core.nsa_attention,
+    nsa/tests/test_causality_asserts.py:54-56): a patched function must be the one that runs."""
     g = globals()
-    if (g["select_topn_ranges_batched"], g["select_topn_ranges_rows"]) == _ORIG_SELECTORS:
+    if (g["select_topn_ranges_batched"], g["select_topn_ranges_rows"], g["selection_scores"]) == _ORIG_SELECTORS:
         return selection_scores_select(Q, K_cmp, meta, n_sel, mode=selector, scale=scale)[1]
-    p_grp = selection_scores(Q, K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
+    p_grp = g["selection_scores"](Q, K_cmp, meta, scale, causal_skip=True, leave_skipped=True)
     if selector == "batched":
         return g["select_topn_ranges_batched"](p_grp, meta, n_sel, S, True, 2)
     return g["select_topn_ranges_rows"](p_grp, meta, n_sel, 0, True, 2)
