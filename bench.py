@@ -756,6 +756,7 @@ def main():
     from nsa_vibe_amd import _lib as _nsa_lib
 
     out["library"] = _nsa_lib.loaded_library()  # which build of libnsa_sel_hip.so ran (NSA_HIP_LIB can point at an A/B build: never the product figure)
+    refused = None
     if rank == 0:
         t_sc, t_sel, t_att, t_sa, Lsum, Lmean, n_tiles, t_scsel = stage_times(nv, meta, Q, Kc, K, V, S, max(5, args.steps // 2))
         gathered = n_tiles * BLK_KEYS * (D + D) * 2
@@ -796,8 +797,8 @@ def main():
                                hbm_traffic=hbm, l2=l2)
         for key in ("frac", "hbm_traffic_frac", "l2_frac"):
             v = out["roofline"][key]
-            if v is not None and not (0.0 <= v <= 1.0):
-                raise SystemExit(f"bench.py: roofline.{key} = {v} is not a fraction of its roof; refusing to print the line")
+            if v is not None and not (0.0 <= v <= 1.0):  # (decided here, acted on below: the other ranks still wait at the final barrier)
+                refused = f"bench.py: roofline.{key} = {v} is not a fraction of its roof; refusing to print the line"
         out["stages_ms"] = {"scores_and_select_one_launch": t_scsel, "attention": t_att, "scores_alone": t_sc, "select_alone": t_sel,
                             "select_and_attention_one_call": t_sa,
                             "note": "per-call HIP-event medians (each call timed alone, with its launch gap); ms_per_step is the back-to-back loop.  "
@@ -859,10 +860,15 @@ def main():
                 extra["error"] = repr(e)
             out["extra"] = extra
             out["cpu_baseline"] = cpu_baseline(S, B)
-        print(json.dumps(out))
+        if refused is None:
+            print(json.dumps(out))
+        else:
+            print(refused, file=sys.stderr)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if refused is not None:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
