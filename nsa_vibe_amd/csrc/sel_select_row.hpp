@@ -56,6 +56,136 @@ __device__ __forceinline__ void extract_runs_lanes(const unsigned long long (&wd
     }
 }
 
+// Threshold (radix) select of the k_actual largest keys of a row spread over the wave -- lane l holds the order-preserving integer images
+// u[c] of candidates lane + 64 c (0 = not a candidate) -- ties at the threshold to the lowest (c, lane), i.e. (key desc, index asc) when the
+// candidates are laid out in ascending index order.  Returns the lane's pick mask (bit c).  Shared by the flat selector below and the two
+// stages of the hierarchical one (select_topn_hier_*).
+template <int CAND, bool SORT_ALL = false>
+__device__ __forceinline__ typename std::conditional<(CAND <= 32), unsigned, unsigned long long>::type threshold_select(const unsigned (&u)[CAND],
+                                                                                                                     const int k_actual) {
+    using mask_t = typename std::conditional<(CAND <= 32), unsigned, unsigned long long>::type;
+    const int lane = lane_id();
+    mask_t sel = 0;
+    constexpr bool SORTED = CAND <= 16 || SORT_ALL;  // beyond 1024 blocks the sorted copy does not fit the fused kernels' register budget
+    unsigned w[CAND];  // per-lane descending copy (Batcher's odd-even merge sort, CAND a power of two)
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) w[c] = u[c];
+    if constexpr (SORTED) {
+#pragma unroll
+        for (int pp = 1; pp < CAND; pp <<= 1)
+#pragma unroll
+            for (int kk = pp; kk >= 1; kk >>= 1)
+#pragma unroll
+                for (int jj = kk % pp; jj + kk < CAND; jj += 2 * kk)
+#pragma unroll
+                    for (int ii = 0; ii < kk; ++ii)
+                        if (ii + jj + kk < CAND && (ii + jj) / (2 * pp) == (ii + jj + kk) / (2 * pp)) {
+                            const unsigned a = w[ii + jj], b = w[ii + jj + kk];
+                            w[ii + jj] = max(a, b);
+                            w[ii + jj + kk] = min(a, b);
+                        }
+    }
+    DEC_TS(22);
+    // counts are capped just above k: the search needs "at least k", and "exactly k" ends it early
+    auto count_ge = [&](unsigned cand, int cap) -> int {
+        int cnt = 0;
+        if constexpr (SORTED && CAND >= 2) {
+            // slots 0 and 1 in straight-line code (most rounds end there: one exit test instead of four), then slot by slot
+            const unsigned long long b0 = __ballot(w[0] >= cand), b1 = __ballot(w[1] >= cand);
+            cnt = __popcll(b0) + __popcll(b1);
+            if (b1 == 0ull || cnt > cap) return cnt;  // (b0 == 0 implies b1 == 0: the slots are sorted per lane)
+#pragma unroll
+            for (int c = 2; c < CAND; ++c) {
+                const unsigned long long b = __ballot(w[c] >= cand);
+                if (b == 0ull) break;
+                cnt += __popcll(b);
+                if (cnt > cap) break;  // exact while <= cap
+            }
+            return cnt;
+        }
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            const unsigned long long b = __ballot(w[c] >= cand);
+            if (SORTED && b == 0ull) break;
+            cnt += __popcll(b);
+            if (SORTED && cnt > cap) break;  // exact while <= cap
+        }
+        return cnt;
+    };
+    const int k_eff = min(k_actual, count_ge(1u, k_actual));  // valid candidates, as far as they matter
+    if (k_eff > 0) {
+        // MSB-first search for the k-th largest key T.  A prefix with EXACTLY k keys at or above it ends the search: those k keys
+        // are the picks whatever the remaining bits are (no tie can straddle the cut) -- typically after ~20 of the 32 rounds.
+        DEC_TS(23);
+        unsigned T = 0;
+        bool exact = false;
+        int bit0 = 31;
+        {
+            // the first nine rounds (sign + exponent of the k-th key) in at most two probes: the k-th largest key cannot exceed the
+            // largest one, M; if at least k keys share M's top nine bits that IS the prefix of the k-th key, otherwise it is tried one
+            // exponent lower (scores of one row rarely spread over more than two octaves), otherwise the search starts from the top bit.
+            // Any prefix P with count(>= P) >= k > count(>= P + 2^23) is the one the bit-by-bit search arrives at: same T, same picks.
+            unsigned lm = w[0];
+            if constexpr (!SORTED) {
+#pragma unroll
+                for (int c = 1; c < CAND; ++c) lm = max(lm, w[c]);
+            }
+            const unsigned p1 = wave_max_u32(lm) & 0xFF800000u;
+            if (p1 != 0u) {
+                const int c1 = count_ge(p1, k_eff);
+                if (c1 >= k_eff) {
+                    T = p1;
+                    bit0 = 22;
+                    exact = c1 == k_eff;
+                } else if (p1 > 0x00800000u) {
+                    const unsigned p2 = p1 - 0x00800000u;
+                    const int c2 = count_ge(p2, k_eff);
+                    if (c2 >= k_eff) {
+                        T = p2;
+                        bit0 = 22;
+                        exact = c2 == k_eff;
+                    }
+                }
+            }
+        }
+        for (int bit = bit0; bit >= 0 && !exact; --bit) {
+            const unsigned cand = T | (1u << bit);
+            const int c = count_ge(cand, k_eff);
+            if (c >= k_eff) T = cand;
+            if (c == k_eff) {
+                exact = true;
+                break;
+            }
+        }
+        DEC_TS(24);
+        if (exact) {
+#pragma unroll
+            for (int c = 0; c < CAND; ++c)
+                if (u[c] >= T) sel |= (mask_t)1 << c;
+        } else {
+            int cnt_gt = 0;  // keys above T: fewer than k_eff by construction
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                const unsigned long long b = __ballot(w[c] > T);
+                if (SORTED && b == 0ull) break;
+                cnt_gt += __popcll(b);
+            }
+            int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
+                if (__ballot(u[c] >= T) == 0ull) continue;
+                const bool eq = u[c] == T;
+                const unsigned long long em = __ballot(eq);
+                const int take = min(__popcll(em), remaining);
+                if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) sel |= (mask_t)1 << c;
+                remaining -= take;
+            }
+        }
+    }
+    return sel;
+}
+
 // one wave: top-n + forced + merge of ONE row.  p = the row's S_sel group scores (global or LDS).  Lane i < min(W, 64) returns
 // range i in (my_s, my_e); ranges beyond the emitted runs are [0, 0).
 // scr: 128 ints of LDS private to the wave, or null.  With it the runs of the selected bitmap are extracted by all lanes at once (a lane
@@ -163,123 +293,7 @@ __device__ __forceinline__ void select_topn_row_regs(const SelectParams &P, cons
             const bool ok = key[c] > -INFINITY;  // forced / masked / NaN candidates never compete
             u[c] = ok ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0u;  // valid keys map to >= 0x00800000
         }
-        constexpr bool SORTED = CAND <= 16 || SORT_ALL;  // beyond 1024 blocks the sorted copy does not fit the fused kernels' register budget
-        unsigned w[CAND];  // per-lane descending copy (Batcher's odd-even merge sort, CAND a power of two)
-#pragma unroll
-        for (int c = 0; c < CAND; ++c) w[c] = u[c];
-        if constexpr (SORTED) {
-#pragma unroll
-            for (int pp = 1; pp < CAND; pp <<= 1)
-#pragma unroll
-                for (int kk = pp; kk >= 1; kk >>= 1)
-#pragma unroll
-                    for (int jj = kk % pp; jj + kk < CAND; jj += 2 * kk)
-#pragma unroll
-                        for (int ii = 0; ii < kk; ++ii)
-                            if (ii + jj + kk < CAND && (ii + jj) / (2 * pp) == (ii + jj + kk) / (2 * pp)) {
-                                const unsigned a = w[ii + jj], b = w[ii + jj + kk];
-                                w[ii + jj] = max(a, b);
-                                w[ii + jj + kk] = min(a, b);
-                            }
-        }
-        DEC_TS(22);
-        // counts are capped just above k: the search needs "at least k", and "exactly k" ends it early
-        auto count_ge = [&](unsigned cand, int cap) -> int {
-            int cnt = 0;
-            if constexpr (SORTED && CAND >= 2) {
-                // slots 0 and 1 in straight-line code (most rounds end there: one exit test instead of four), then slot by slot
-                const unsigned long long b0 = __ballot(w[0] >= cand), b1 = __ballot(w[1] >= cand);
-                cnt = __popcll(b0) + __popcll(b1);
-                if (b1 == 0ull || cnt > cap) return cnt;  // (b0 == 0 implies b1 == 0: the slots are sorted per lane)
-#pragma unroll
-                for (int c = 2; c < CAND; ++c) {
-                    const unsigned long long b = __ballot(w[c] >= cand);
-                    if (b == 0ull) break;
-                    cnt += __popcll(b);
-                    if (cnt > cap) break;  // exact while <= cap
-                }
-                return cnt;
-            }
-#pragma unroll
-            for (int c = 0; c < CAND; ++c) {
-                const unsigned long long b = __ballot(w[c] >= cand);
-                if (SORTED && b == 0ull) break;
-                cnt += __popcll(b);
-                if (SORTED && cnt > cap) break;  // exact while <= cap
-            }
-            return cnt;
-        };
-        const int k_eff = min(P.k_actual, count_ge(1u, P.k_actual));  // valid candidates, as far as they matter
-        if (k_eff > 0) {
-            // MSB-first search for the k-th largest key T.  A prefix with EXACTLY k keys at or above it ends the search: those k keys
-            // are the picks whatever the remaining bits are (no tie can straddle the cut) -- typically after ~20 of the 32 rounds.
-            DEC_TS(23);
-            unsigned T = 0;
-            bool exact = false;
-            int bit0 = 31;
-            {
-                // the first nine rounds (sign + exponent of the k-th key) in at most two probes: the k-th largest key cannot exceed the
-                // largest one, M; if at least k keys share M's top nine bits that IS the prefix of the k-th key, otherwise it is tried one
-                // exponent lower (scores of one row rarely spread over more than two octaves), otherwise the search starts from the top bit.
-                // Any prefix P with count(>= P) >= k > count(>= P + 2^23) is the one the bit-by-bit search arrives at: same T, same picks.
-                unsigned lm = w[0];
-                if constexpr (!SORTED) {
-#pragma unroll
-                    for (int c = 1; c < CAND; ++c) lm = max(lm, w[c]);
-                }
-                const unsigned p1 = wave_max_u32(lm) & 0xFF800000u;
-                if (p1 != 0u) {
-                    const int c1 = count_ge(p1, k_eff);
-                    if (c1 >= k_eff) {
-                        T = p1;
-                        bit0 = 22;
-                        exact = c1 == k_eff;
-                    } else if (p1 > 0x00800000u) {
-                        const unsigned p2 = p1 - 0x00800000u;
-                        const int c2 = count_ge(p2, k_eff);
-                        if (c2 >= k_eff) {
-                            T = p2;
-                            bit0 = 22;
-                            exact = c2 == k_eff;
-                        }
-                    }
-                }
-            }
-            for (int bit = bit0; bit >= 0 && !exact; --bit) {
-                const unsigned cand = T | (1u << bit);
-                const int c = count_ge(cand, k_eff);
-                if (c >= k_eff) T = cand;
-                if (c == k_eff) {
-                    exact = true;
-                    break;
-                }
-            }
-            DEC_TS(24);
-            if (exact) {
-#pragma unroll
-                for (int c = 0; c < CAND; ++c)
-                    if (u[c] >= T) selbits |= (mask_t)1 << c;
-            } else {
-                int cnt_gt = 0;  // keys above T: fewer than k_eff by construction
-#pragma unroll
-                for (int c = 0; c < CAND; ++c) {
-                    const unsigned long long b = __ballot(w[c] > T);
-                    if (SORTED && b == 0ull) break;
-                    cnt_gt += __popcll(b);
-                }
-                int remaining = k_eff - cnt_gt;  // >= 1 slots for the keys equal to T, lowest index first
-                const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-                for (int c = 0; c < CAND; ++c) {  // ascending c then ascending lane = ascending block index
-                    if (__ballot(u[c] >= T) == 0ull) continue;
-                    const bool eq = u[c] == T;
-                    const unsigned long long em = __ballot(eq);
-                    const int take = min(__popcll(em), remaining);
-                    if (u[c] > T || (eq && __popcll(em & lt_mask) < take)) selbits |= (mask_t)1 << c;
-                    remaining -= take;
-                }
-            }
-        }
+        selbits |= threshold_select<CAND, SORT_ALL>(u, P.k_actual);
     }
 
     DEC_TS(25);
