@@ -34,8 +34,8 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- tuning switches -------------------------------------------------------------------------
-static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP", "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2", "SCORES_SELECT"};
-static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, -1, -1, -1, 0, -1, -1, 1, -1, -1, -1, -1, -1};
+static const char *const g_tune_names[TUNE_COUNT] = {"SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP", "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2", "SCORES_SELECT", "DECODE_BAND"};
+static const int g_tune_defaults[TUNE_COUNT] = {-1, -1, 1, 1, -1, -1, -1, 1, 1, 0, -1, -1, -1, 0, -1, -1, 1, -1, -1, -1, -1, -1, -1};
 static std::atomic<int> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -656,7 +656,9 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
                               const float *csc_vals, int32_t *ranges_out, void *O, int B, int G, int h, int Dk, int Dv, int S_cmp, int S_sel,
                               int S_kv, int l, int d, int l_sel, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb,
                               int64_t ksg, int64_t kss, int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *workspace,
-                              size_t workspace_bytes, void *stream, int defer, int *ns_used, float **part_used) {
+                              size_t workspace_bytes, void *stream, int defer, int *ns_used, float **part_used, const DecBandPair *band,
+                              int *band_taken) {
+    if (band_taken) *band_taken = 0;
     NSA_CHECK_ARG(workspace && ((uintptr_t)workspace % 16 == 0) &&
                       workspace_bytes >= nsa_sel_decode_step_workspace(B, G, h, Dk, Dv, S_cmp, S_sel, n_top, dtype),
                   "decode_step: workspace missing, misaligned or too small");
@@ -673,8 +675,9 @@ int nsa::sel_decode_step_impl(const void *Q, const void *K_cmp, const void *K, c
     if (decode_step_supported((int64_t)B * G, dtype, h, Dk, Dv, S_cmp, S_sel, S_kv, l, d, l_sel, n_top, t_token, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg, vss, Q, K_cmp,
                               K, V)) {  // scores -> statistics -> Eq.9/10 -> sequential top-n -> selection attention: ONE launch, O is final
         if (ns_used) *ns_used = 1;
+        if (band && band_taken) *band_taken = 1;
         return launch_decode_step(Q, K_cmp, K, V, O, ranges_out, B, G, h, S_cmp, S_sel, S_kv, n_top, t_token, kcb, kcg, kcs, ksb, ksg, kss, vsb, vsg,
-                                  vss, dtype, sc, w, a, (hipStream_t)stream);
+                                  vss, dtype, sc, w, a, (hipStream_t)stream, band_taken ? band : nullptr);
     }
     (void)wg_attn;
     if (decode_score_select_supported(dtype, h, Dk, S_cmp, S_sel, kcb, kcg, kcs, Q, K_cmp, (int64_t)B * G)) {

@@ -314,21 +314,17 @@ static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv
     F.w1 = L->gate_w1; F.b1 = L->gate_b1; F.w2 = L->gate_w2; F.b2 = L->gate_b2;
     F.R = (int64_t)B * G; F.h = h; F.Dk = Dk; F.Dv = Dv; F.Hd = L->gate_hidden; F.tau = L->gate_tau;
     F.O[0] = Ocmp; F.O[1] = Osel; F.O[2] = Owin;
-    // 4. selected branch
-    float *sel_part = nullptr;
-    if (int rc = sel_decode_step_impl(Q, kv->K_cmp, kv->K_sel, kv->V_sel, csc_ptr, csc_rows, csc_vals, ranges, Osel, B, G, h, Dk, Dv, n_cmp,
-                                      S_sel, S_raw, L->l, L->d, L->l_sel, L->n_sel, t, kcb, kcg, Dk, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale,
-                                      ws + W.sel, W.sel_bytes, stream, defer, &F.ns[1], &sel_part))
-        return rc;
-    F.part[1] = sel_part;
-    // 5. sliding and compressed branches: one launch when both run in split-KV form
+    // 4 + 5. the three branches.  The sliding and the compressed branch run in split-KV form with the combine left to the finish kernel; when
+    // the selected branch runs as the one-launch decode step they ride on ITS launch (workgroups behind the step's own: sel_decode_fused.hip),
+    // otherwise they are one launch of their own.
     int ns_band = 1;
     band_attn_workspace(B, 1, G, h, Dk, Dv, dt, &ns_band);
     const bool dual = defer && ns_band > 1 && n_cmp > 0 && L->w > 0 && band_attn_mfma_supported(dt, h, Dk, Dv) &&
                       ((uintptr_t)kv->K_win % 16 == 0) && ((uintptr_t)kv->V_win % 16 == 0) && ((uintptr_t)kv->K_cmp % 16 == 0) &&
                       ((uintptr_t)kv->V_cmp % 16 == 0) && ksb * 2 < ((int64_t)1 << 31) && vsb * 2 < ((int64_t)1 << 31);
+    DecBandPair BP{};
+    BandAttnParams &PW = BP.w, &PC = BP.c;
     if (dual) {
-        BandAttnParams PW{}, PC{};
         PW.Q = Q; PW.K = kv->K_win; PW.V = kv->V_win; PW.O = Owin;
         PW.B = B; PW.S = 1; PW.G = G; PW.h = h; PW.Dk = Dk; PW.Dv = Dv; PW.S_kv = S_raw;
         PW.ksb = ksb; PW.ksg = ksg; PW.kss = Dk; PW.vsb = vsb; PW.vsg = vsg; PW.vss = Dv;
@@ -339,7 +335,18 @@ static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv
         PC.ksb = kcb; PC.ksg = kcg; PC.vsb = vcb; PC.vsg = vcg;
         PC.a = L->l; PC.dd = L->d; PC.c = 1; PC.w = 1 << 30;
         PC.part = (float *)(ws + W.band2);
-        if (int rc = launch_band_attn_fwd_dual(PW, PC, dt, st)) return rc;
+    }
+    const bool ride = dual && Dk == 64 && tuning(TUNE_DECODE_BAND) != 0;
+    float *sel_part = nullptr;
+    int band_taken = 0;
+    if (int rc = sel_decode_step_impl(Q, kv->K_cmp, kv->K_sel, kv->V_sel, csc_ptr, csc_rows, csc_vals, ranges, Osel, B, G, h, Dk, Dv, n_cmp,
+                                      S_sel, S_raw, L->l, L->d, L->l_sel, L->n_sel, t, kcb, kcg, Dk, ksb, ksg, Dk, vsb, vsg, Dv, dt, scale,
+                                      ws + W.sel, W.sel_bytes, stream, defer, &F.ns[1], &sel_part, ride ? &BP : nullptr, &band_taken))
+        return rc;
+    F.part[1] = sel_part;
+    if (dual) {
+        if (!band_taken)
+            if (int rc = launch_band_attn_fwd_dual(PW, PC, dt, st)) return rc;
         F.ns[2] = F.ns[0] = ns_band;
         F.part[2] = PW.part;
         F.part[0] = PC.part;

@@ -75,6 +75,15 @@ bool band_attn_mfma_supported(int dtype, int h, int Dk, int Dv);
 size_t band_attn_workspace(int B, int S, int G, int h, int Dk, int Dv, int dtype, int *nsplit_out);
 int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st);
 int launch_band_attn_fwd_dual(const BandAttnParams &P0, const BandAttnParams &P1, int dtype, hipStream_t st);
+// the sliding (w) and compressed (c) branch of a decode step as extra workgroups of ANOTHER launch (the one-launch decode step of the
+// selected branch): workgroups [n_sel, n_sel + n_w) take w, those behind them c; every wave of such a workgroup is one (row, split) unit
+struct DecBandPair {
+    BandAttnParams w, c;
+    unsigned n_sel;  // workgroups of the host kernel's own work (0xffffffff: the launch carries no band work)
+    unsigned n_w;    // workgroups of the sliding branch
+};
+// fills tpw of both argument blocks and returns the (row, split) units = waves of each; false: not both in split form with deferred combine
+bool band_dual_plan(BandAttnParams *P0, BandAttnParams *P1, int dtype, int64_t waves[2]);
 int launch_band_attn_bwd_dq(const BandAttnParams &P, const void *dO, const float *lse, const float *delta, void *dQ, int dtype,
                             hipStream_t st);
 int launch_bwd_delta(const void *O, const void *dO, float *delta, int64_t n_rows, int Dv, int dtype, hipStream_t st);

@@ -28,6 +28,7 @@
 #include "sel_attn_decode.hpp"
 #include "sel_attn_params.hpp"
 #include "sel_select_row.hpp"
+#include "band_attn_fwd_body.hpp"
 
 namespace nsa {
 
@@ -61,6 +62,20 @@ static size_t dstep_lds(int nw) { return (size_t)nw * DEC_ATT_TILE + DSTEP_TAIL 
 // forced blocks have landed, moving that traffic back onto the critical path)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Workgroups behind the step's own (BP.n_sel ...) carry the sliding and the compressed branch of a layer step (nsa_layer_decode_step): the two
+// are independent of the selected branch, and as a launch of their own they cost the step ~7 us of kernel plus a launch gap on a chain of
+// five dependent launches.  Every wave of such a workgroup is one (row, key split) unit of band_attn_body's split form (wave-private LDS
+// in the V tile of the wave, no workgroup barrier); they are dispatched behind the step's own workgroups, so a team of the split form finds
+// its members resident as before.
+template <typename T, int NW>
+__device__ __forceinline__ bool decode_band_workgroup(const DecBandPair &BP) {
+    if (blockIdx.x < BP.n_sel) return false;
+    const unsigned bb = blockIdx.x - BP.n_sel;
+    if (bb < BP.n_w) band_attn_body<T, 64, 1, true, 1>(BP.w, bb, NW);
+    else band_attn_body<T, 64, 1, true, 1>(BP.c, bb - BP.n_w, NW);
+    return true;
+}
+
 // CPW = chunks of 64 compressed rows per wave.  2: the logits of both stay in the MFMA accumulators (contexts to 32 NW chunks).  4 (round 4,
 // unsplit only): a row of up to 4 NW chunks in ONE workgroup -- 64k contexts on 16 waves, 32k on 8 -- for batches whose rows times a team's
 // workgroups do not fit the chip together (B >= 128 at 64k: a team must be co-resident, R NS <= slots): the first chunk's logits stay in
@@ -68,8 +83,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // wrote, so no barrier guards them) until the row's log-sum-exp is known.  Two chunks (16 KiB per wave) are in flight throughout.  Same
 // arithmetic on the same values: p_grp, ranges and O have the bits of every other form.
 template <typename T, int NW, bool SPLIT, int HC, int CPW = 2>
-__global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT) {
+__global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT, DecBandPair BP) {
     static_assert(CPW == 2 || (CPW == 4 && !SPLIT), "four chunks per wave: unsplit form only");
+    if (decode_band_workgroup<T, NW>(BP)) return;
     using M = MfmaT<T>;
     using x8 = typename M::x8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -476,7 +492,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_step_kernel(DecStepParams P
 // of the exact forms wherever the 13th / 14th ranking keys are further apart than that -- the contract for scores computed from Q / K
 //  -- and exact-tie order is only guaranteed by the exact forms.  The plan picks this form only where they do not apply.
 template <typename T, int NW, int HC>
-__global__ __launch_bounds__(NW * 64, 4) void decode_step_onepass_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT) {
+__global__ __launch_bounds__(NW * 64, 4) void decode_step_onepass_kernel(DecStepParams P, SelectParams SP, int cand, DecAttnArgs AT, DecBandPair BP) {
+    if (decode_band_workgroup<T, NW>(BP)) return;
     using M = MfmaT<T>;
     using x8 = typename M::x8;
     constexpr int CPW = 8;
@@ -797,7 +814,7 @@ bool decode_step_supported(int64_t R, int dtype, int h, int Dk, int Dv, int S_cm
 
 int launch_decode_step(const void *Q, const void *Kc, const void *K, const void *V, void *O, int32_t *ranges_out, int B, int G, int h, int S_cmp,
                        int S_sel, int S_kv, int n_top, int t_token, int64_t kcb, int64_t kcg, int64_t kcs, int64_t ksb, int64_t ksg, int64_t kss,
-                       int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *ws, size_t ws_bytes, hipStream_t st) {
+                       int64_t vsb, int64_t vsg, int64_t vss, int dtype, float scale, void *ws, size_t ws_bytes, hipStream_t st, const DecBandPair *band) {
     const int64_t R = (int64_t)B * G;
     NSA_CHECK_ARG(R >= 1 && R <= (1 << 24), "decode step: bad row count");
     const int nchunk = ((S_cmp + 63) / 64);
@@ -824,7 +841,7 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
     const int c = (S_sel + 63) / 64;
     const int cand = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : c <= 16 ? 16 : 32;
     const DecAttnArgs AT{Q, K, V, O, G, h, S_kv, n_top, ksb, ksg, kss, vsb, vsg, vss, scale * LOG2E};
-    void (*k)(DecStepParams, SelectParams, int, DecAttnArgs);
+    void (*k)(DecStepParams, SelectParams, int, DecAttnArgs, DecBandPair);
     const bool bf = dtype == NSA_DT_BF16, split = ns > 1;
 #define NSA_DSK(NW_, SP_, HC_) (bf ? decode_step_kernel<__bf16, NW_, SP_, HC_> : decode_step_kernel<_Float16, NW_, SP_, HC_>)
 #define NSA_DSK4(NW_, HC_) (bf ? decode_step_kernel<__bf16, NW_, false, HC_, 4> : decode_step_kernel<_Float16, NW_, false, HC_, 4>)
@@ -854,8 +871,21 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
                 }
         }
     }
-    const int64_t grid = ns > 1 ? ((R + 7) / 8) * 8 * ns : R;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nw * 64), lds, st, P, SP, cand, AT);
+    int64_t grid = ns > 1 ? ((R + 7) / 8) * 8 * ns : R;
+    DecBandPair BP{};
+    BP.n_sel = 0xffffffffu;
+    if (band) {  // the layer step's sliding + compressed branches on workgroups behind the step's own (decode_band_workgroup)
+        BP = *band;
+        int64_t waves[2];
+        NSA_CHECK_ARG(BP.w.Dk == 64 && BP.w.Dv == 64 && band_dual_plan(&BP.w, &BP.c, dtype, waves), "decode step: band branches not in split form");
+        const int64_t gw = (waves[0] + nw - 1) / nw, gc = (waves[1] + nw - 1) / nw;
+        NSA_CHECK_ARG(grid + gw + gc < ((int64_t)1 << 31), "decode step: too many workgroups");
+        BP.n_sel = (unsigned)grid;
+        BP.n_w = (unsigned)gw;
+        grid += gw + gc;
+    }
+    static_assert(2 * Geo<64>::TILE_BYTES <= DEC_ATT_TILE, "a band wave keeps its K and V tile in the wave's V tile of the step");
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nw * 64), lds, st, P, SP, cand, AT, BP);
     NSA_LAUNCH_CHECK("decode_step");
     return NSA_OK;
 }

@@ -406,6 +406,11 @@ class NSAAttention(nn.Module):
         else:
             assert x.shape[1] == 1, f"Decode mode requires S=1 (single token), got S={x.shape[1]}."
         self._check_kv(x, kv)
+        # a strided [B,S,dim] view (e.g. x[:, :S] of a longer buffer) is copied first: the projection would otherwise run as a strided-batched
+        # GEMM, and PyTorch 2.10 + rocm7.0 returns wrong values from that route at some shapes (3 x 2100 x 768 -> 1536, bf16: errors of
+        # several units, a memory fault when the result is consumed; tools/dbg_gemm.py) -- the contiguous 2-D GEMM is correct
+        if not x.is_contiguous():
+            x = x.contiguous()
         one_call = self._native_ok(x)
         try:
             return self._prefill(x, kv) if prefill else self._decode(x, kv)
