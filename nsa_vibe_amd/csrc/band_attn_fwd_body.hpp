@@ -3,6 +3,7 @@
 // run the sliding and the compressed branch of a layer step on workgroups behind those of the selected branch.
 #pragma once
 #include "attn_mfma_tiles.hpp"
+#include "layer_gate.hpp"
 
 namespace nsa {
 
@@ -10,7 +11,10 @@ namespace nsa {
 // next iteration): the compute-bound NT = 3 form spends ~19 % of a tile issuing its 8 DMA instructions, plain loads issue faster.
 template <typename T, int D, int NT, bool SPLIT, int STAGE>
 // WPB: waves of a workgroup that take band work (SPLIT form: every wave is its own unit; the plain kernels run 4)
-__device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const unsigned bid, const int wpb = 4) {
+// mg (SPLIT, S = 1 only): BandMergeArgs of sel_attn_params.hpp -- merge the unit's splits here; eval_gates: this launch's branch also
+// evaluates the gate probabilities of its rows
+__device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const unsigned bid, const int wpb = 4, const BandMergeArgs *mg = nullptr,
+                                               const bool eval_gates = false) {
     using M = MfmaT<T>;
     using G_ = Geo<D>;
     using x8 = typename M::x8;
@@ -285,7 +289,16 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         float ltot = lrun[n] + __shfl_xor(lrun[n], 16, 64);
         ltot += __shfl_xor(ltot, 32, 64);
         if (orow[n] < 0) continue;
-        if (SPLIT) {
+        if (SPLIT && mg && mg->on) {
+            // the record of this split goes to the wave's own tile space (its K / V tiles are consumed): [head][PART_PAD + D]
+            float *pr = (float *)kl + (int)(orow[n] % h) * (D + PART_PAD);
+            if (q == 0) {
+                pr[0] = mrun[n];
+                pr[1] = ltot;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) *(f32x4 *)(pr + PART_PAD + 16 * m + 4 * q) = o[n][m];
+        } else if (SPLIT) {
             // partial record [row][sp][head][PART_PAD + D] in the layout of the selection kernel's combine pass
             const int64_t row = orow[n] / h;
             const int head = (int)(orow[n] - row * h);
@@ -307,6 +320,45 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
                 *(x4 *)(Or + 16 * m + 4 * q) = ov;
             }
             if (P.lse && q == 0) P.lse[orow[n]] = ltot > 0.f ? (mrun[n] + __builtin_amdgcn_logf(ltot)) * LN2 : -INFINITY;
+        }
+    }
+    if constexpr (SPLIT && NT == 1 && D == 64) {
+        if (mg && mg->on) {
+            // ---- merge of the unit's nsplit records (waves wave - sp .. of this workgroup), heads dealt over the unit's waves; one lane per
+            // column.  The decode finish kernel's arithmetic (layer_fused.hip: 16 clamped steps, weights of the missing splits 0).
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int ns = P.nsplit;
+            const float *u0 = (const float *)(smem + (size_t)(wave - sp) * (2 * G_::TILE_BYTES));
+            constexpr int SST = 2 * G_::TILE_BYTES / 4;  // floats between the records of consecutive splits
+            const int64_t row = ((int64_t)b * P.S + tw0) * P.G + g;
+            for (int hh = sp; hh < h; hh += ns) {
+                const float *base = u0 + hh * (D + PART_PAD);
+                const float mv = lane < ns ? base[lane * SST] : -INFINITY;
+                const float lv = lane < ns ? base[lane * SST + 1] : 0.f;
+                float pv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) pv[s] = base[min(s, ns - 1) * SST + PART_PAD + lane];
+                const float mmax = wave_max(mv);
+                const float w = (mv == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mv - mmax);
+                const float ltot = wave_sum(lv * w);
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = fmaf(pv[s], __shfl(w, s, 64), acc);
+                ((T *)P.O)[(row * h + hh) * D + lane] = Elt<T>::from_f(acc * (ltot > 0.f ? 1.f / ltot : 0.f));
+            }
+            if (eval_gates && sp == ns - 1) {  // (the unit's last wave: the one with the fewest heads to merge)
+                float *sqp = (float *)(kl + 3 * G_::TILE_BYTES / 2);  // 256 floats behind this wave's record (h <= 16: 4352 bytes)
+                const T *Qr = (const T *)P.Q + row * h * D;
+                float pr[3];
+                if (mg->Hd <= 32 && h <= 8) {
+                    GateFast<T> gf;
+                    gf.load(Qr, h, mg->Hd, mg->gw1, mg->gb1, mg->gw2, mg->gb2);
+                    gf.compute(h, mg->Hd, mg->tau, sqp, pr);
+                } else {
+                    gate_probs<T>(Qr, h, D, mg->Hd, mg->gw1, mg->gb1, mg->gw2, mg->gb2, mg->tau, sqp, pr);
+                }
+                if (lane < 3) mg->gates[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
+            }
         }
     }
 }

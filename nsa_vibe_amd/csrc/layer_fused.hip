@@ -7,15 +7,13 @@
 //   * gate MLP + 3-branch combine (nsa_attention.py:32-82, 85-124)
 // Arithmetic follows the PyTorch operator chain the reference runs, including where it rounds to the activation dtype
 // (rnd() below), so a bf16 module gives the same numbers whether these kernels or the eager ops are used.
+#include <type_traits>
+
 #include "attn_mfma_tiles.hpp"
 #include "layer_fused.hpp"
+#include "layer_gate.hpp"
 
 namespace nsa {
-
-template <typename T>
-__device__ __forceinline__ float rnd(float x) {
-    return Elt<T>::to_f(Elt<T>::from_f(x));
-}
 
 // rotate the pair (x0, x1) of pair index i (of D/2) at position pos
 template <typename T>
@@ -32,29 +30,6 @@ __device__ __forceinline__ void rope_pair(float x0, float x1, int i, int D, floa
 }
 
 // ------------------------------------------------------------------------------------------ small-M linear
-// 8 consecutive elements as floats (16-byte loads when `vec`, i.e. K % 8 == 0 and 16-byte aligned rows)
-template <typename T>
-__device__ __forceinline__ void load8(const T *p, int nvalid, bool vec, float (&out)[8]) {
-    if (vec) {
-        if constexpr (sizeof(T) == 2) {
-            const u32x4 raw = *(const u32x4 *)p;
-            const T *e = (const T *)&raw;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = Elt<T>::to_f(e[j]);
-        } else {
-            const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                out[j] = a[j];
-                out[4 + j] = b[j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = j < nvalid ? Elt<T>::to_f(p[j]) : 0.f;
-    }
-}
-
 // one wave per output column n (W row n stays in registers), rows of A in chunks of 8
 // RMSNorm folded into a small-M projection: rsqrt(mean(x^2) + eps) of one row, computed by the whole wave with the rounding points
 // of the eager chain (llama_block_nsa.py:16-19); the caller then feeds rnd(rnd(x * r) * g) into its dot products
@@ -153,6 +128,41 @@ __global__ __launch_bounds__(256) void linear_gemv4_kernel(const T *__restrict__
             const float sum = wave_sum(acc[c][r]);
             if (lane == 0 && n0 + c < N) out[(int64_t)r * N + n0 + c] = Elt<T>::from_f(linear_epilogue<T>(sum, epi, res, (int64_t)r * N + n0 + c));
         }
+}
+
+// decode, few rows: the three-branch mix as the A operand of the output projection -- A[r, k] = g_cmp O_cmp + g_sel O_sel + g_win O_win of
+// group k / (K / G) with the gate probabilities gates[r G + g][3] (evaluated by the launch that produced the branches), rounded to the
+// activation dtype exactly where the mix kernel rounds (mix3), so this is decode_finish + linear_small in one launch, same bits
+template <typename T>
+__global__ __launch_bounds__(256) void linear_small_mix_kernel(const T *__restrict__ Oc, const T *__restrict__ Os, const T *__restrict__ Ow,
+                                                               const float *__restrict__ gates, const T *__restrict__ W, T *__restrict__ out, int M,
+                                                               int N, int K, int G, int epi, const T *__restrict__ res) {
+    const int lane = lane_id();
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const T *w = W + (int64_t)n * K;
+    const int kpg = K / G;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 8; k < K; k += 512) {
+        float wv[8];
+        load8<T>(w + k, K - k, true, wv);
+        const int g = k / kpg;
+        for (int r = 0; r < M; ++r) {
+            float oc[8], os[8], ow[8];
+            const int64_t o = (int64_t)r * K + k;
+            load8<T>(Oc + o, 8, true, oc);
+            load8<T>(Os + o, 8, true, os);
+            load8<T>(Ow + o, 8, true, ow);
+            const float *gp = gates + ((int64_t)r * G + g) * 3;
+            const float pr[3] = {gp[0], gp[1], gp[2]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], rnd<T>(mix3<T>(pr, oc[j], os[j], ow[j])), acc[r]);
+        }
+    }
+    for (int r = 0; r < M; ++r) {
+        const float s = wave_sum(acc[r]);
+        if (lane == 0) out[(int64_t)r * N + n] = Elt<T>::from_f(linear_epilogue<T>(s, epi, res, (int64_t)r * N + n));
+    }
 }
 
 template <typename T>
@@ -396,9 +406,17 @@ __global__ __launch_bounds__(256, 2) void qkv_rope_append_kernel(RopeAppendParam
 // C^T[n, m] = W[n,:] . X[m,:]: W rows are the MFMA A operand (each W element is fetched once, straight from global in
 // fragment shape), the rows of X the B operand (L1/L2 resident), all loads of a wave issued before its first MFMA; the four
 // K-partials meet in LDS.  Thread t of the epilogue owns row m = t % 64 and columns 4 (t / 64) .. +3 (two rotation pairs).
-template <typename T, bool ROPE>
+// MIX (decode output projection): the rows of X are the three-branch mix, formed on the fly from X = O_cmp, mx.Os, mx.Ow and the row
+// gates mx.gates[m G + g][3] with the rounding of the mix kernel (the same operand values as decode_finish + this kernel: same bits)
+struct LinearMixArgs {
+    const void *Os, *Ow;
+    const float *gates;
+    int G;
+};
+template <typename T, bool ROPE, bool MIX = false>
 __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
-                                                          T *__restrict__ out, int M, int N, int K, int epi, const T *__restrict__ res) {
+                                                          T *__restrict__ out, int M, int N, int K, int epi, const T *__restrict__ res,
+                                                          LinearMixArgs mx) {
     using MT_ = MfmaT<T>;
     using x8 = typename MT_::x8;
     __shared__ float part[4][16][65];
@@ -410,6 +428,49 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P,
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const T *wrow = W + (int64_t)min(n0 + rho, N - 1) * K + 8 * q;  // the last column tile may be partial: clamp, store guarded
+    if constexpr (MIX) {
+        const int kpg = K / mx.G;
+        const int nmt = min(4, (M - m0 + 15) >> 4);  // 16-row tiles that hold a row (the plain form computes clamped duplicates instead)
+        auto run = [&](auto RC) {
+            constexpr int R = decltype(RC)::value;  // k-steps in flight: 3 R (nmt + 1) + ... loads per round
+            for (int sb = s0; sb < s1; sb += R) {
+                x8 wf[R], oc[R][4], os[R][4], ow[R][4];
+                float pr[R][4][3];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int s = min(sb + i, s1 - 1);
+                    wf[i] = *(const x8 *)(wrow + 32 * s);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        if (mt < nmt) {
+                            const int m = min(m0 + 16 * mt + rho, M - 1);
+                            const int64_t o = (int64_t)m * K + 32 * s + 8 * q;
+                            oc[i][mt] = *(const x8 *)(X + o);
+                            os[i][mt] = *(const x8 *)((const T *)mx.Os + o);
+                            ow[i][mt] = *(const x8 *)((const T *)mx.Ow + o);
+                            const float *gp = mx.gates + ((int64_t)m * mx.G + (32 * s + 8 * q) / kpg) * 3;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) pr[i][mt][k] = gp[k];
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    if (sb + i < s1) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            if (mt < nmt) {
+                                x8 xm;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    xm[j] = Elt<T>::from_f(mix3<T>(pr[i][mt], Elt<T>::to_f(oc[i][mt][j]), Elt<T>::to_f(os[i][mt][j]), Elt<T>::to_f(ow[i][mt][j])));
+                                acc[mt] = MT_::mma(wf[i], xm, acc[mt]);
+                            }
+                    }
+            }
+        };
+        if (nmt == 1) run(std::integral_constant<int, 6>{});
+        else run(std::integral_constant<int, 2>{});
+    } else
     for (int sb = s0; sb < s1; sb += 6) {  // 6 k-steps (30 loads) in flight per round
         x8 wf[6], xf[6][4];
 #pragma unroll
@@ -465,8 +526,8 @@ int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int 
     if (linear_mfma_ok(dtype, M, N, K, A, W)) {
         RopeAppendParams P{};
         const dim3 g2((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
-        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res);
-        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res);
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res, LinearMixArgs{});
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res, LinearMixArgs{});
         NSA_LAUNCH_CHECK("linear_small(mfma)");
         return NSA_OK;
     }
@@ -474,6 +535,35 @@ int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int 
 }
 // RMSNorm(x) folded into the projection (rows <= 8: the VALU kernel); returns NSA_ERR_INVALID without side effects when not applicable
 bool linear_small_can_fold_norm(int dtype, int M, int N, int K, const void *A, const void *W) { return !linear_mfma_ok(dtype, M, N, K, A, W); }
+bool linear_small_mix_supported(int dtype, int M, int N, int K, int G, const void *Oc, const void *Os, const void *Ow, const void *W) {
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 1 && G >= 1 && K % (32 * G) == 0 && N >= 1 &&
+           (((uintptr_t)Oc | (uintptr_t)Os | (uintptr_t)Ow | (uintptr_t)W) % 16 == 0);
+}
+
+// rows 1-2: the VALU dot products of linear_small_kernel; from 3 on: the MFMA kernel (what launch_linear_small_epi picks for a ready-made A)
+int launch_linear_small_mix(const void *Oc, const void *Os, const void *Ow, const float *gates, const void *W, void *out, int M, int N, int K, int G,
+                            int dtype, int epi, const void *res, hipStream_t st) {
+    NSA_CHECK_ARG(linear_small_mix_supported(dtype, M, N, K, G, Oc, Os, Ow, W) && gates && out, "linear_small_mix: unsupported shape");
+    const bool bf = dtype == NSA_DT_BF16;
+    if (linear_mfma_ok(dtype, M, N, K, Oc, W)) {
+        const dim3 g2((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
+        const RopeAppendParams P{};
+        const LinearMixArgs mx{Os, Ow, gates, G};
+        if (bf) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false, true>), g2, dim3(256), 0, st, P, (const __bf16 *)Oc, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res, mx);
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false, true>), g2, dim3(256), 0, st, P, (const _Float16 *)Oc, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res, mx);
+    } else {
+        const dim3 grid((unsigned)((N + 3) / 4));
+        if (bf)
+            hipLaunchKernelGGL(linear_small_mix_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)Oc, (const __bf16 *)Os, (const __bf16 *)Ow, gates,
+                               (const __bf16 *)W, (__bf16 *)out, M, N, K, G, epi, (const __bf16 *)res);
+        else
+            hipLaunchKernelGGL(linear_small_mix_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16 *)Oc, (const _Float16 *)Os, (const _Float16 *)Ow,
+                               gates, (const _Float16 *)W, (_Float16 *)out, M, N, K, G, epi, (const _Float16 *)res);
+    }
+    NSA_LAUNCH_CHECK("linear_small_mix");
+    return NSA_OK;
+}
+
 int launch_linear_small_norm(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, const void *norm_w,
                              float eps, hipStream_t st) {
     return launch_linear_small_valu(A, W, out, M, N, K, dtype, epi, res, norm_w, eps, st);
@@ -493,8 +583,8 @@ int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void 
     if (linear_mfma_ok(dtype, P.B, NT, K, X, W)) {
         NSA_CHECK_ARG(norm_w == nullptr, "qkv_rope_append: the MFMA form takes normalised input");
         const dim3 g2((unsigned)((NT + 15) / 16), (unsigned)((P.B + 63) / 64));
-        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K, 0, (const __bf16 *)nullptr);
-        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K, 0, (const _Float16 *)nullptr);
+        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, true>), g2, dim3(256), 0, st, P, (const __bf16 *)X, (const __bf16 *)W, (__bf16 *)nullptr, P.B, NT, K, 0, (const __bf16 *)nullptr, LinearMixArgs{});
+        else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, true>), g2, dim3(256), 0, st, P, (const _Float16 *)X, (const _Float16 *)W, (_Float16 *)nullptr, P.B, NT, K, 0, (const _Float16 *)nullptr, LinearMixArgs{});
         NSA_LAUNCH_CHECK("qkv_rope_append(mfma)");
         return NSA_OK;
     }
@@ -777,142 +867,6 @@ int launch_rmsnorm_rows_bwd(const void *x, const void *w, const void *dy, void *
 // ------------------------------------------------------------------------------------------ gate MLP + combine
 // one wave per (b, s, g) row: q_pooled = mean_h Q -> fc1 -> silu -> fc2 -> / tau -> softmax (one-hot when the top two
 // logits are more than 50 apart, nsa_attention.py:70-81) -> O = g_cmp O_cmp + g_sel O_sel + g_win O_win
-// gate probabilities of one row (wave-cooperative; sqp = 256 wave-private floats)
-template <typename T>
-__device__ __forceinline__ void gate_probs(const T *Qr, int h, int Dk, int Hd, const void *w1_, const void *b1_, const void *w2_,
-                                           const void *b2_, float tau, float *sqp, float (&pr)[3]) {
-    const int lane = lane_id();
-    for (int dk = lane; dk < Dk; dk += 64) {
-        float a = 0.f;
-        for (int hh = 0; hh < h; ++hh) a += Elt<T>::to_f(Qr[hh * Dk + dk]);
-        sqp[dk] = rnd<T>(a / (float)h);
-    }
-    wave_lds_fence();
-    // fc1 + silu + fc2: hidden unit j = j0 + lane % 32, the two half-waves split the Dk axis of its dot product (16-byte
-    // weight loads); the fc2 contributions of the units are summed over the lanes at the end
-    float g3[3] = {0.f, 0.f, 0.f};
-    {
-        const int half = lane >> 5, dspan = (Dk + 1) >> 1, d0 = half * dspan, d1 = min(Dk, d0 + dspan);
-        const bool vec = (dspan % 8 == 0) && ((uintptr_t)w1_ % 16 == 0);
-        for (int j0 = 0; j0 < Hd; j0 += 32) {
-            const int j = j0 + (lane & 31);
-            float a = 0.f;
-            if (j < Hd) {
-                const T *w1 = (const T *)w1_ + (int64_t)j * Dk;
-                for (int dk = d0; dk < d1; dk += 8) {
-                    float wv[8];
-                    load8<T>(w1 + dk, d1 - dk, vec, wv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (dk + e < d1) a = fmaf(wv[e], sqp[dk + e], a);
-                }
-            }
-            const float other = __shfl_xor(a, 32, 64);
-            a = half == 0 ? a + other : other + a;  // low half + high half on both lanes
-            if (j < Hd && half == 0) {
-                a = rnd<T>(a + Elt<T>::to_f(((const T *)b1_)[j]));
-                const float act = rnd<T>(a / (1.f + expf(-a)));  // silu
-#pragma unroll
-                for (int k = 0; k < 3; ++k) g3[k] = fmaf(Elt<T>::to_f(((const T *)w2_)[k * Hd + j]), act, g3[k]);
-            }
-        }
-    }
-    float gl[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        gl[k] = rnd<T>(wave_sum(g3[k]) + Elt<T>::to_f(((const T *)b2_)[k]));
-        gl[k] = rnd<T>(gl[k] / fmaxf(tau, 1e-6f));
-    }
-    const float mx = fmaxf(gl[0], fmaxf(gl[1], gl[2]));
-    float den = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        pr[k] = expf(gl[k] - mx);
-        den += pr[k];
-    }
-    int arg = 0;
-    if (gl[1] > gl[arg]) arg = 1;
-    if (gl[2] > gl[arg]) arg = 2;
-    float second = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (k != arg) second = fmaxf(second, gl[k]);
-    const bool peaked = (gl[arg] - second) > 50.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pr[k] = peaked ? (k == arg ? 1.f : 0.f) : rnd<T>(pr[k] / den);
-}
-
-// The m7c geometry (Dk = 64, hidden <= 32, h <= 8) with every global load issued up front and no data-dependent branch
-// before the arithmetic: in decode this kernel is a handful of waves and its time is the length of its load -> use chains.
-// Same arithmetic, same rounding points as gate_probs.
-template <typename T>
-struct GateFast {
-    float qv[8], w1v[4][8], b1v, w2v[3], b2v[3];
-    __device__ __forceinline__ void load(const T *Qr, int h, int Hd, const void *w1_, const void *b1_, const void *w2_, const void *b2_) {
-        const int lane = lane_id(), j = min(lane & 31, Hd - 1), half = lane >> 5;
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) qv[hh] = Elt<T>::to_f(Qr[min(hh, h - 1) * 64 + lane]);
-        const T *w1 = (const T *)w1_ + (int64_t)j * 64 + 32 * half;
-        const bool vec = ((uintptr_t)w1_ % 16) == 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) load8<T>(w1 + 8 * c, 8, vec, w1v[c]);
-        b1v = Elt<T>::to_f(((const T *)b1_)[j]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            w2v[k] = Elt<T>::to_f(((const T *)w2_)[k * Hd + j]);
-            b2v[k] = Elt<T>::to_f(((const T *)b2_)[k]);
-        }
-    }
-    __device__ __forceinline__ void compute(int h, int Hd, float tau, float *sqp, float (&pr)[3]) const {
-        const int lane = lane_id(), half = lane >> 5;
-        float a = 0.f;
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) a += hh < h ? qv[hh] : 0.f;
-        sqp[lane] = rnd<T>(a / (float)h);
-        wave_lds_fence();
-        a = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(w1v[c][e], sqp[32 * half + 8 * c + e], a);
-        const float other = __shfl_xor(a, 32, 64);
-        a = half == 0 ? a + other : other + a;
-        a = rnd<T>(a + b1v);
-        const float act = rnd<T>(a / (1.f + expf(-a)));
-        const bool mine = half == 0 && (lane & 31) < Hd;
-        float gl[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            gl[k] = rnd<T>(wave_sum(mine ? w2v[k] * act : 0.f) + b2v[k]);
-            gl[k] = rnd<T>(gl[k] / fmaxf(tau, 1e-6f));
-        }
-        const float mx = fmaxf(gl[0], fmaxf(gl[1], gl[2]));
-        float den = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            pr[k] = expf(gl[k] - mx);
-            den += pr[k];
-        }
-        int arg = 0;
-        if (gl[1] > gl[arg]) arg = 1;
-        if (gl[2] > gl[arg]) arg = 2;
-        float second = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k != arg) second = fmaxf(second, gl[k]);
-        const bool peaked = (gl[arg] - second) > 50.0f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pr[k] = peaked ? (k == arg ? 1.f : 0.f) : rnd<T>(pr[k] / den);
-    }
-};
-
-template <typename T>
-__device__ __forceinline__ float mix3(const float (&pr)[3], float oc, float os, float ow) {
-    const float t1 = rnd<T>(pr[0] * oc), t2 = rnd<T>(pr[1] * os);
-    const float t3 = rnd<T>(t1 + t2), t4 = rnd<T>(pr[2] * ow);
-    return t3 + t4;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) {
     __shared__ float sqp[4][256];

@@ -46,6 +46,10 @@ bool linear_small_can_fold_norm(int dtype, int M, int N, int K, const void *A, c
 int launch_linear_small_norm(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, const void *norm_w,
                              float eps, hipStream_t st);
 int launch_decode_finish(const DecodeFinishParams &P, int dtype, hipStream_t st);
+// output projection of a decode step fed by the three branch outputs and the row gates (few rows: M <= 8): out = mix(O_cmp, O_sel, O_win) . W^T
+bool linear_small_mix_supported(int dtype, int M, int N, int K, int G, const void *Oc, const void *Os, const void *Ow, const void *W);
+int launch_linear_small_mix(const void *Oc, const void *Os, const void *Ow, const float *gates, const void *W, void *out, int M, int N, int K, int G,
+                            int dtype, int epi, const void *res, hipStream_t st);
 int launch_linear_small(const void *A, const void *W, void *out, int M, int N, int K, int dtype, hipStream_t st);
 // epi: 0 none, 1 silu, 2 + res[M,N]
 int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int N, int K, int dtype, int epi, const void *res, hipStream_t st);

@@ -57,7 +57,7 @@ enum Tune {
     TUNE_SEL_KSPLIT_T1,     // NSA_HIP_SEL_KSPLIT_T1 / _T2: key-split attention, rows from this position on (position = row + S_kv - S) are split 2-way / 4-way; -1 = 32768 / never
     TUNE_SEL_KSPLIT_T2,
     TUNE_SCORES_SELECT,     // NSA_HIP_SCORES_SELECT: nsa_sel_scores_select, 1 = the top-n selection of a query tile always runs inside the scorer launch (32x32x16 form), 0 = always its own launch, -1 = inside from 48k contexts on (S_cmp >= 3072: where it is faster)
-    TUNE_DECODE_BAND,       // NSA_HIP_DECODE_BAND: layer decode step, the sliding + compressed branches ride on the launch of the one-launch decode step of the selected branch (-1 / 1, default) or run as their own launch (0)
+    TUNE_DECODE_BAND,       // NSA_HIP_DECODE_BAND: layer decode step, the sliding + compressed branches: 0 = their own launch; 1 = on the launch of the selected branch's one-launch decode step, splits merged by the finish kernel; 2 = the same with the splits merged by the workgroup that holds them (branch outputs and gates final); 3 / -1 (default) = 2 + with <= 8 rows the gate mix is the A operand of the output projection (three launches per step)
     TUNE_COUNT
 };
 int tuning(Tune t);

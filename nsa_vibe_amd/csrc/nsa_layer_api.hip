@@ -234,7 +234,7 @@ int nsa_layer_prefill(const nsa_layer_desc *L, const nsa_kv_desc *kv, const void
 
 // workspace: proj | Q | O_cmp | O_sel | O_win | O_mix | ranges | selection-decode scratch | band scratch
 struct DecodeWs {
-    size_t proj, q, ocmp, osel, owin, omix, ranges, sel, band, band2, total, sel_bytes, band_bytes;
+    size_t proj, q, ocmp, osel, owin, omix, ranges, gates, sel, band, band2, total, sel_bytes, band_bytes;
 };
 static DecodeWs decode_ws(const nsa_layer_desc *L, int B, int S_max) {
     DecodeWs w;
@@ -251,6 +251,7 @@ static DecodeWs decode_ws(const nsa_layer_desc *L, int B, int S_max) {
     w.owin = o; o += up256(B * NO * e);
     w.omix = o; o += up256(B * NO * e);
     w.ranges = o; o += up256(sizeof(int32_t) * (size_t)B * L->G * L->n_sel * 2);
+    w.gates = o; o += up256(sizeof(float) * (size_t)B * L->G * 3);
     w.sel_bytes = nsa_sel_decode_step_workspace(B, L->G, L->h, L->Dk, L->Dv, n_cmp_max, S_sel_max, L->n_sel, L->dtype);
     w.sel = o; o += up256(w.sel_bytes);
     w.band_bytes = nsa_band_attn_fwd_workspace(B, 1, L->G, L->h, L->Dk, L->Dv, L->dtype);
@@ -336,7 +337,16 @@ static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv
         PC.a = L->l; PC.dd = L->d; PC.c = 1; PC.w = 1 << 30;
         PC.part = (float *)(ws + W.band2);
     }
-    const bool ride = dual && Dk == 64 && tuning(TUNE_DECODE_BAND) != 0;
+    const int band_mode = tuning(TUNE_DECODE_BAND);  // 0 own launch, 1 ride, 2 ride + merge in the workgroup, -1 / 3: 2 + the mix in the output projection
+    const bool ride = dual && Dk == 64 && band_mode != 0;
+    float *gates = gates_out ? gates_out : (float *)(ws + W.gates);
+    if (ride && band_mode != 1 && h <= 16) {
+        BP.mg.on = 1;
+        BP.mg.Hd = L->gate_hidden;
+        BP.mg.tau = L->gate_tau;
+        BP.mg.gw1 = L->gate_w1; BP.mg.gb1 = L->gate_b1; BP.mg.gw2 = L->gate_w2; BP.mg.gb2 = L->gate_b2;
+        BP.mg.gates = gates;
+    }
     float *sel_part = nullptr;
     int band_taken = 0;
     if (int rc = sel_decode_step_impl(Q, kv->K_cmp, kv->K_sel, kv->V_sel, csc_ptr, csc_rows, csc_vals, ranges, Osel, B, G, h, Dk, Dv, n_cmp,
@@ -344,7 +354,16 @@ static int layer_decode_step_impl(const nsa_layer_desc *L, const nsa_kv_desc *kv
                                       ws + W.sel, W.sel_bytes, stream, defer, &F.ns[1], &sel_part, ride ? &BP : nullptr, &band_taken))
         return rc;
     F.part[1] = sel_part;
-    if (dual) {
+    if (dual && band_taken && BP.mg.on) {
+        // O_win, O_cmp (merged by the workgroups that held their splits), O_sel and the row gates are final: with few rows the mix is the
+        // A operand of the output projection -- three launches per step
+        F.ns[2] = F.ns[0] = 1;
+        // (measured: the mix in the projection wins up to 32 rows -- 43.3 -> 40.5 us at B = 32 -- and loses from 64 on, where every one of the
+        // projection's 48 workgroups would redo the mix of all rows: 47.1 -> 50.6 us; DECODE_BAND = 3 takes it at any batch)
+        if (((band_mode < 0 && B <= 32) || band_mode == 3) && F.ns[1] == 1 &&
+            linear_small_mix_supported(dt, B, L->dim, NO, G, Ocmp, Osel, Owin, L->W_out) && Dv == 64)
+            return launch_linear_small_mix(Ocmp, Osel, Owin, gates, L->W_out, y, B, L->dim, NO, G, dt, residual ? 2 : 0, residual, st);
+    } else if (dual) {
         if (!band_taken)
             if (int rc = launch_band_attn_fwd_dual(PW, PC, dt, st)) return rc;
         F.ns[2] = F.ns[0] = ns_band;

@@ -77,8 +77,19 @@ int launch_band_attn_fwd_mfma(const BandAttnParams &P, int dtype, hipStream_t st
 int launch_band_attn_fwd_dual(const BandAttnParams &P0, const BandAttnParams &P1, int dtype, hipStream_t st);
 // the sliding (w) and compressed (c) branch of a decode step as extra workgroups of ANOTHER launch (the one-launch decode step of the
 // selected branch): workgroups [n_sel, n_sel + n_w) take w, those behind them c; every wave of such a workgroup is one (row, split) unit
+// mg.on: the splits of a (row, branch) unit are the consecutive waves of ONE workgroup (nsplit divides the workgroup's waves) and are merged
+// through LDS by those waves -- the branch output O is final in the activation dtype (the arithmetic of the decode finish kernel's merge, bit
+// for bit), no partial record goes to memory; the sliding branch's unit also evaluates the row's gate probabilities into gates [R,3]
+struct BandMergeArgs {
+    int on;
+    int Hd;
+    float tau;
+    const void *gw1, *gb1, *gw2, *gb2;  // gate MLP (fc1 weight / bias, fc2 weight / bias)
+    float *gates;
+};
 struct DecBandPair {
     BandAttnParams w, c;
+    BandMergeArgs mg;
     unsigned n_sel;  // workgroups of the host kernel's own work (0xffffffff: the launch carries no band work)
     unsigned n_w;    // workgroups of the sliding branch
 };

@@ -71,8 +71,8 @@ template <typename T, int NW>
 __device__ __forceinline__ bool decode_band_workgroup(const DecBandPair &BP) {
     if (blockIdx.x < BP.n_sel) return false;
     const unsigned bb = blockIdx.x - BP.n_sel;
-    if (bb < BP.n_w) band_attn_body<T, 64, 1, true, 1>(BP.w, bb, NW);
-    else band_attn_body<T, 64, 1, true, 1>(BP.c, bb - BP.n_w, NW);
+    if (bb < BP.n_w) band_attn_body<T, 64, 1, true, 1>(BP.w, bb, NW, &BP.mg, true);
+    else band_attn_body<T, 64, 1, true, 1>(BP.c, bb - BP.n_w, NW, &BP.mg, false);
     return true;
 }
 
@@ -878,6 +878,13 @@ int launch_decode_step(const void *Q, const void *Kc, const void *K, const void 
         BP = *band;
         int64_t waves[2];
         NSA_CHECK_ARG(BP.w.Dk == 64 && BP.w.Dv == 64 && band_dual_plan(&BP.w, &BP.c, dtype, waves), "decode step: band branches not in split form");
+        if (BP.mg.on) {  // splits merged by the workgroup that holds them: a unit = nsplit consecutive waves of one workgroup
+            NSA_CHECK_ARG(BP.w.S == 1 && BP.c.S == 1 && BP.mg.gates && BP.w.O && BP.c.O && h <= 16, "decode step: band merge needs S = 1, outputs and a gate buffer");
+            int nsm = 1;
+            while (2 * nsm <= BP.w.nsplit && 2 * nsm <= nw) nsm *= 2;
+            BP.w.nsplit = BP.c.nsplit = nsm;
+            waves[0] = waves[1] = R * nsm;
+        }
         const int64_t gw = (waves[0] + nw - 1) / nw, gc = (waves[1] + nw - 1) / nw;
         NSA_CHECK_ARG(grid + gw + gc < ((int64_t)1 << 31), "decode step: too many workgroups");
         BP.n_sel = (unsigned)grid;
