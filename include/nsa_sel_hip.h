@@ -70,7 +70,7 @@ NSA_API const char *nsa_hip_last_error(void);
 /* Measurement / A-B switches (kernel form, staging, mapping).  Each switch is seeded once per process from the environment
  * variable NSA_HIP_<NAME> and can be changed afterwards only through this call (nothing reads the environment on the launch
  * path).  name: "SEL_ROWS", "ATTN_MAP", "ATTN_STAGE", "BAND_STAGE", "DECODE_UNFUSED", "SEL_BLOCKS", "DECODE_WG", "SEL_ROWSUM", "DECODE_STENCIL", "SEL_FUSE", "SCORES_FORM", "SEL_FLAT", "SEL_KSPLIT", "DECODE_STOP" (TIMELINE builds
- * only), "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2", "SCORES_SELECT" (with or without the NSA_HIP_ prefix); value -1 = automatic where the switch has an automatic setting.  Results never depend on a switch beyond the
+ * only), "DECODE_WAVES", "DECODE_SPLIT", "DECODE_STEP", "DECODE_TEAM_SPIN", "DECODE_WIDE", "SEL_KSPLIT_T1", "SEL_KSPLIT_T2", "SCORES_SELECT", "DECODE_BAND" (with or without the NSA_HIP_ prefix); value -1 = automatic where the switch has an automatic setting.  Results never depend on a switch beyond the
  * tolerances stated for the entry point. */
 NSA_API int nsa_hip_set_tuning(const char *name, int value);
 NSA_API int nsa_hip_get_tuning(const char *name, int *value);
