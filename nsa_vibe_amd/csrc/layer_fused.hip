@@ -15,18 +15,52 @@
 
 namespace nsa {
 
-// rotate the pair (x0, x1) of pair index i (of D/2) at position pos
+// rotation of pair index i (of D/2) at position pos: (sin, cos) rounded to the activation dtype as the eager chain has them
 template <typename T>
-__device__ __forceinline__ void rope_pair(float x0, float x1, int i, int D, float pos, float base, float inv_scale, float &r0, float &r1) {
+__device__ __forceinline__ void rope_sincos(int i, int D, float pos, float base, float inv_scale, float &sn, float &cs) {
     const float e = (-2.0f * (float)i) / (float)D;
     const float inv_freq = powf(base, e);
     const float ang = (pos * inv_scale) * inv_freq;
-    float sn, cs;
     sincosf(ang, &sn, &cs);
     sn = rnd<T>(sn);
     cs = rnd<T>(cs);
+}
+template <typename T>
+__device__ __forceinline__ void rope_rotate(float x0, float x1, float sn, float cs, float &r0, float &r1) {
     r0 = rnd<T>(rnd<T>(x0 * cs) - rnd<T>(x1 * sn));
     r1 = rnd<T>(rnd<T>(x0 * sn) + rnd<T>(x1 * cs));
+}
+// rotate the pair (x0, x1) of pair index i (of D/2) at position pos
+template <typename T>
+__device__ __forceinline__ void rope_pair(float x0, float x1, int i, int D, float pos, float base, float inv_scale, float &r0, float &r1) {
+    float sn, cs;
+    rope_sincos<T>(i, D, pos, base, inv_scale, sn, cs);
+    rope_rotate<T>(x0, x1, sn, cs, r0, r1);
+}
+
+// 8 elements of the activation dtype held raw (one 16-byte load) -> floats
+template <typename T>
+__device__ __forceinline__ void raw8(const u32x4 &raw, float (&out)[8]) {
+    static_assert(sizeof(T) == 2, "raw8: 16-bit element types");
+    const T *e = (const T *)&raw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = Elt<T>::to_f(e[j]);
+}
+// sum of squares of a row held raw in up to two chunks per lane, with row_rms's rounding (chunk c valid when has[c])
+template <typename T>
+__device__ __forceinline__ float row_rms_raw(const u32x4 (&x)[2], bool has1, int K, float eps) {
+    float acc = 0.f, v[8];
+    raw8<T>(x[0], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += rnd<T>(v[j] * v[j]);
+    if (has1) {
+        raw8<T>(x[1], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += rnd<T>(v[j] * v[j]);
+    }
+    float r = rnd<T>(wave_sum(acc) / (float)K);
+    r = rnd<T>(r + eps);
+    return rnd<T>(1.0f / sqrtf(r));
 }
 
 // ------------------------------------------------------------------------------------------ small-M linear
@@ -130,10 +164,159 @@ __global__ __launch_bounds__(256) void linear_gemv4_kernel(const T *__restrict__
         }
 }
 
+// Latency forms of the two kernels above for 1-2 rows of 16-bit activations with K <= 512 NC (16-byte aligned rows): a decode step is a
+// chain of such launches and each is as long as its chain of dependent memory round trips -- the generic k loops wait for the loads of
+// one 512-element chunk before they issue the next (fc2 at K = 3072: six round trips in a row).  Here every load of the wave (weights,
+// norm weights, the rows of A) goes out before the first use; the arithmetic is the generic kernels' in the same order (same bits).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void linear_small_fast_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M, int N,
+                                                                int K, int epi, const T *__restrict__ res, const T *__restrict__ norm_w,
+                                                                float norm_eps) {
+    const int lane = lane_id();
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const T *w = W + (int64_t)n * K;
+    u32x4 wr[NC], gr[NC], ar[2][NC];
+    bool has[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = lane * 8 + 512 * c;
+        has[c] = k < K;
+        const int kc = min(k, K - 8);
+        wr[c] = *(const u32x4 *)(w + kc);
+        if (norm_w) gr[c] = *(const u32x4 *)(norm_w + kc);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) ar[r][c] = *(const u32x4 *)(A + (int64_t)r * K + kc);
+    }
+    float rms[2] = {1.f, 1.f};
+    if (norm_w) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (has[c]) {
+                        float v[8];
+                        raw8<T>(ar[r][c], v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc += rnd<T>(v[j] * v[j]);
+                    }
+                float q = rnd<T>(wave_sum(acc) / (float)K);
+                q = rnd<T>(q + norm_eps);
+                rms[r] = rnd<T>(1.0f / sqrtf(q));
+            }
+    }
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (has[c]) {
+            float wv[8], gv[8], av[8];
+            raw8<T>(wr[c], wv);
+            if (norm_w) raw8<T>(gr[c], gv);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (r < M) {
+                    raw8<T>(ar[r][c], av);
+                    if (norm_w) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) av[j] = rnd<T>(rnd<T>(av[j] * rms[r]) * gv[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], av[j], acc[r]);
+                }
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (r < M) {
+            const float sum = wave_sum(acc[r]);
+            if (lane == 0) out[(int64_t)r * N + n] = Elt<T>::from_f(linear_epilogue<T>(sum, epi, res, (int64_t)r * N + n));
+        }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void linear_gemv4_fast_kernel(const T *__restrict__ A, const T *__restrict__ W, T *__restrict__ out, int M, int N,
+                                                                int K, int epi, const T *__restrict__ res, const T *__restrict__ norm_w,
+                                                                float norm_eps) {
+    const int lane = lane_id();
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (n0 >= N) return;
+    u32x4 wr[4][NC], gr[NC], ar[2][NC];
+    bool has[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = lane * 8 + 512 * c;
+        has[c] = k < K;
+        const int kc = min(k, K - 8);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) wr[cc][c] = *(const u32x4 *)(W + (int64_t)min(n0 + cc, N - 1) * K + kc);
+        if (norm_w) gr[c] = *(const u32x4 *)(norm_w + kc);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) ar[r][c] = *(const u32x4 *)(A + (int64_t)r * K + kc);
+    }
+    float rms[2] = {1.f, 1.f};
+    if (norm_w) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (has[c]) {
+                        float v[8];
+                        raw8<T>(ar[r][c], v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc += rnd<T>(v[j] * v[j]);
+                    }
+                float q = rnd<T>(wave_sum(acc) / (float)K);
+                q = rnd<T>(q + norm_eps);
+                rms[r] = rnd<T>(1.0f / sqrtf(q));
+            }
+    }
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (has[c]) {
+            float gv[8], av[2][8];
+            if (norm_w) raw8<T>(gr[c], gv);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (r < M) {
+                    raw8<T>(ar[r][c], av[r]);
+                    if (norm_w) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) av[r][j] = rnd<T>(rnd<T>(av[r][j] * rms[r]) * gv[j]);
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (r < M) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        float wv[8];
+                        raw8<T>(wr[cc][c], wv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[cc][r] = fmaf(wv[j], av[r][j], acc[cc][r]);
+                    }
+                }
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (r < M) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float sum = wave_sum(acc[cc][r]);
+                if (lane == 0 && n0 + cc < N) out[(int64_t)r * N + n0 + cc] = Elt<T>::from_f(linear_epilogue<T>(sum, epi, res, (int64_t)r * N + n0 + cc));
+            }
+        }
+}
+
 // decode, few rows: the three-branch mix as the A operand of the output projection -- A[r, k] = g_cmp O_cmp + g_sel O_sel + g_win O_win of
 // group k / (K / G) with the gate probabilities gates[r G + g][3] (evaluated by the launch that produced the branches), rounded to the
 // activation dtype exactly where the mix kernel rounds (mix3), so this is decode_finish + linear_small in one launch, same bits
-template <typename T>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void linear_small_mix_kernel(const T *__restrict__ Oc, const T *__restrict__ Os, const T *__restrict__ Ow,
                                                                const float *__restrict__ gates, const T *__restrict__ W, T *__restrict__ out, int M,
                                                                int N, int K, int G, int epi, const T *__restrict__ res) {
@@ -142,32 +325,74 @@ __global__ __launch_bounds__(256) void linear_small_mix_kernel(const T *__restri
     if (n >= N) return;
     const T *w = W + (int64_t)n * K;
     const int kpg = K / G;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 8; k < K; k += 512) {
-        float wv[8];
-        load8<T>(w + k, K - k, true, wv);
-        const int g = k / kpg;
-        for (int r = 0; r < M; ++r) {
-            float oc[8], os[8], ow[8];
-            const int64_t o = (int64_t)r * K + k;
-            load8<T>(Oc + o, 8, true, oc);
-            load8<T>(Os + o, 8, true, os);
-            load8<T>(Ow + o, 8, true, ow);
-            const float *gp = gates + ((int64_t)r * G + g) * 3;
-            const float pr[3] = {gp[0], gp[1], gp[2]};
+    // (M <= 2, K <= 512 NC: every load of the wave out before the first use, like linear_small_fast_kernel)
+    u32x4 wr[NC], ocr[2][NC], osr[2][NC], owr[2][NC];
+    float pr[2][NC][3];
+    bool has[NC];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], rnd<T>(mix3<T>(pr, oc[j], os[j], ow[j])), acc[r]);
+    for (int c = 0; c < NC; ++c) {
+        const int k = lane * 8 + 512 * c;
+        has[c] = k < K;
+        const int kc = min(k, K - 8), g = kc / kpg;
+        wr[c] = *(const u32x4 *)(w + kc);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) {
+                const int64_t o = (int64_t)r * K + kc;
+                ocr[r][c] = *(const u32x4 *)(Oc + o);
+                osr[r][c] = *(const u32x4 *)(Os + o);
+                owr[r][c] = *(const u32x4 *)(Ow + o);
+                const float *gp = gates + ((int64_t)r * G + g) * 3;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pr[r][c][i] = gp[i];
+            }
+    }
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (has[c]) {
+            float wv[8];
+            raw8<T>(wr[c], wv);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (r < M) {
+                    float oc[8], os[8], ow[8];
+                    raw8<T>(ocr[r][c], oc);
+                    raw8<T>(osr[r][c], os);
+                    raw8<T>(owr[r][c], ow);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], rnd<T>(mix3<T>(pr[r][c], oc[j], os[j], ow[j])), acc[r]);
+                }
         }
-    }
-    for (int r = 0; r < M; ++r) {
-        const float s = wave_sum(acc[r]);
-        if (lane == 0) out[(int64_t)r * N + n] = Elt<T>::from_f(linear_epilogue<T>(s, epi, res, (int64_t)r * N + n));
-    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (r < M) {
+            const float sum = wave_sum(acc[r]);
+            if (lane == 0) out[(int64_t)r * N + n] = Elt<T>::from_f(linear_epilogue<T>(sum, epi, res, (int64_t)r * N + n));
+        }
 }
 
 template <typename T>
 static int linear_small_t(const void *A, const void *W, void *out, int M, int N, int K, int epi, const void *res, const void *norm_w, float eps,
                           hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        const bool fast = M <= 2 && K >= 8 && K % 8 == 0 && K <= 4096 && (((uintptr_t)A | (uintptr_t)W) % 16 == 0) &&
+                          (!norm_w || (uintptr_t)norm_w % 16 == 0);
+        if (fast) {
+            const int nc = (K + 511) / 512;
+            const bool g4 = N >= 4096 && nc <= 2;
+            const dim3 grid(g4 ? (unsigned)((N + 15) / 16) : (unsigned)((N + 3) / 4));
+#define NSA_LSF(KERN, NC_) hipLaunchKernelGGL((KERN<T, NC_>), grid, dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K, epi, (const T *)res, (const T *)norm_w, eps)
+            if (g4) NSA_LSF(linear_gemv4_fast_kernel, 2);
+            else if (nc <= 2) NSA_LSF(linear_small_fast_kernel, 2);
+            else if (nc <= 4) NSA_LSF(linear_small_fast_kernel, 4);
+            else if (nc <= 6) NSA_LSF(linear_small_fast_kernel, 6);
+            else NSA_LSF(linear_small_fast_kernel, 8);
+#undef NSA_LSF
+            NSA_LAUNCH_CHECK("linear_small(fast)");
+            return NSA_OK;
+        }
+    }
     if (M <= 2 && N >= 4096)
         hipLaunchKernelGGL(linear_gemv4_kernel<T>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, (const T *)A, (const T *)W, (T *)out, M, N, K,
                            epi, (const T *)res, (const T *)norm_w, eps);
@@ -402,6 +627,112 @@ __global__ __launch_bounds__(256, 2) void qkv_rope_append_kernel(RopeAppendParam
     }
 }
 
+// latency form of qkv_rope_append_kernel for 1-2 rows, K <= 512 NC (see linear_small_fast_kernel): every load out first, the pair's
+// rotation (powf + sincosf, ~1 us of arithmetic that depends on the position only) evaluated while they are in flight
+template <typename T, int NC>
+__global__ __launch_bounds__(256, 2) void qkv_rope_append_fast_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W, int K,
+                                                                   const T *__restrict__ norm_w, float norm_eps) {
+    const int lane = lane_id();
+    const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
+    const int NT = NQ + 3 * GK + 3 * GV;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (2 * pair >= NT) return;
+    const T *w0 = W + (int64_t)(2 * pair) * K, *w1 = w0 + K;
+    const int M = P.B;  // S == 1, M <= 2
+    u32x4 u0r[NC], u1r[NC], gr[NC], xr[2][NC];
+    bool has[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = lane * 8 + 512 * c;
+        has[c] = k < K;
+        const int kc = min(k, K - 8);
+        u0r[c] = *(const u32x4 *)(w0 + kc);
+        u1r[c] = *(const u32x4 *)(w1 + kc);
+        if (norm_w) gr[c] = *(const u32x4 *)(norm_w + kc);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) xr[r][c] = *(const u32x4 *)(X + (int64_t)r * K + kc);
+    }
+    // destination and rotation of this wave's column pair (rope_store_pair's cases)
+    const int col = 2 * pair;
+    const float pos = (float)P.t0;
+    float sn = 0.f, cs = 1.f;
+    bool rot;
+    T *dst;
+    int64_t dst_row;  // elements between the rows b of the destination
+    if (col < NQ) {
+        rot = true;
+        rope_sincos<T>(col >> 1, NQ, pos, P.rope_base, P.inv_scale, sn, cs);
+        dst = (T *)P.Q_out + col;
+        dst_row = NQ;
+    } else {
+        int c = col - NQ;
+        const int pairw = GK + GV;
+        const int sp = c / pairw;
+        c -= sp * pairw;
+        const bool isv = c >= GK;
+        if (isv) c -= GK;
+        const int D = isv ? P.Dv : P.Dk;
+        const int g = c / D, dc = c - g * D;
+        rot = !isv && sp < 2;
+        if (rot) rope_sincos<T>(dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, sn, cs);
+        dst = (T *)P.cache[2 * sp + (isv ? 1 : 0)] + ((int64_t)g * P.S_max + P.t0) * D + dc;
+        dst_row = (int64_t)P.G * P.S_max * D;
+    }
+    float rms[2] = {1.f, 1.f};
+    if (norm_w) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r < M) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (has[c]) {
+                        float v[8];
+                        raw8<T>(xr[r][c], v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc += rnd<T>(v[j] * v[j]);
+                    }
+                float q = rnd<T>(wave_sum(acc) / (float)K);
+                q = rnd<T>(q + norm_eps);
+                rms[r] = rnd<T>(1.0f / sqrtf(q));
+            }
+    }
+    float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (has[c]) {
+            float u0[8], u1[8], gv[8], xv[8];
+            raw8<T>(u0r[c], u0);
+            raw8<T>(u1r[c], u1);
+            if (norm_w) raw8<T>(gr[c], gv);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (r < M) {
+                    raw8<T>(xr[r][c], xv);
+                    if (norm_w) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = rnd<T>(rnd<T>(xv[j] * rms[r]) * gv[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        a0[r] = fmaf(u0[j], xv[j], a0[r]);
+                        a1[r] = fmaf(u1[j], xv[j], a1[r]);
+                    }
+                }
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (r < M) {
+            float x0 = rnd<T>(wave_sum(a0[r])), x1 = rnd<T>(wave_sum(a1[r]));  // the projection output in the activation dtype
+            if (rot) rope_rotate<T>(x0, x1, sn, cs, x0, x1);
+            if (lane == 0) {
+                dst[r * dst_row] = Elt<T>::from_f(x0);
+                dst[r * dst_row + 1] = Elt<T>::from_f(x1);
+            }
+        }
+}
+
 // ---- MFMA form for 9 <= M rows (batched decode): workgroup = 16 output columns x 64 rows, the 4 waves split the K axis.
 // C^T[n, m] = W[n,:] . X[m,:]: W rows are the MFMA A operand (each W element is fetched once, straight from global in
 // fragment shape), the rows of X the B operand (L1/L2 resident), all loads of a wave issued before its first MFMA; the four
@@ -536,7 +867,7 @@ int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int 
 // RMSNorm(x) folded into the projection (rows <= 8: the VALU kernel); returns NSA_ERR_INVALID without side effects when not applicable
 bool linear_small_can_fold_norm(int dtype, int M, int N, int K, const void *A, const void *W) { return !linear_mfma_ok(dtype, M, N, K, A, W); }
 bool linear_small_mix_supported(int dtype, int M, int N, int K, int G, const void *Oc, const void *Os, const void *Ow, const void *W) {
-    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 1 && G >= 1 && K % (32 * G) == 0 && N >= 1 &&
+    return (dtype == NSA_DT_BF16 || dtype == NSA_DT_F16) && M >= 1 && G >= 1 && K % (32 * G) == 0 && N >= 1 && (M >= 3 || K <= 2048) &&
            (((uintptr_t)Oc | (uintptr_t)Os | (uintptr_t)Ow | (uintptr_t)W) % 16 == 0);
 }
 
@@ -552,13 +883,17 @@ int launch_linear_small_mix(const void *Oc, const void *Os, const void *Ow, cons
         if (bf) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false, true>), g2, dim3(256), 0, st, P, (const __bf16 *)Oc, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res, mx);
         else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false, true>), g2, dim3(256), 0, st, P, (const _Float16 *)Oc, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res, mx);
     } else {
+        NSA_CHECK_ARG(M <= 2 && K <= 2048, "linear_small_mix: the VALU form takes 1-2 rows of at most 2048 elements");
         const dim3 grid((unsigned)((N + 3) / 4));
-        if (bf)
-            hipLaunchKernelGGL(linear_small_mix_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)Oc, (const __bf16 *)Os, (const __bf16 *)Ow, gates,
-                               (const __bf16 *)W, (__bf16 *)out, M, N, K, G, epi, (const __bf16 *)res);
-        else
-            hipLaunchKernelGGL(linear_small_mix_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16 *)Oc, (const _Float16 *)Os, (const _Float16 *)Ow,
-                               gates, (const _Float16 *)W, (_Float16 *)out, M, N, K, G, epi, (const _Float16 *)res);
+#define NSA_LSM(T_, NC_) hipLaunchKernelGGL((linear_small_mix_kernel<T_, NC_>), grid, dim3(256), 0, st, (const T_ *)Oc, (const T_ *)Os, (const T_ *)Ow, gates, (const T_ *)W, (T_ *)out, M, N, K, G, epi, (const T_ *)res)
+        if (K <= 1024) {
+            if (bf) NSA_LSM(__bf16, 2);
+            else NSA_LSM(_Float16, 2);
+        } else {
+            if (bf) NSA_LSM(__bf16, 4);
+            else NSA_LSM(_Float16, 4);
+        }
+#undef NSA_LSM
     }
     NSA_LAUNCH_CHECK("linear_small_mix");
     return NSA_OK;
@@ -589,6 +924,19 @@ int launch_qkv_rope_append(const RopeAppendParams &P, const void *X, const void 
         return NSA_OK;
     }
     const dim3 grid((unsigned)((NT / 2 + 3) / 4)), block(256);
+    if (dtype != NSA_DT_F32 && P.B <= 2 && P.S == 1 && K >= 8 && K % 8 == 0 && K <= 2048 && (((uintptr_t)X | (uintptr_t)W) % 16 == 0) &&
+        (!norm_w || (uintptr_t)norm_w % 16 == 0)) {
+        const bool bf = dtype == NSA_DT_BF16;
+        if (K <= 1024) {
+            if (bf) hipLaunchKernelGGL((qkv_rope_append_fast_kernel<__bf16, 2>), grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K, (const __bf16 *)norm_w, norm_eps);
+            else hipLaunchKernelGGL((qkv_rope_append_fast_kernel<_Float16, 2>), grid, block, 0, st, P, (const _Float16 *)X, (const _Float16 *)W, K, (const _Float16 *)norm_w, norm_eps);
+        } else {
+            if (bf) hipLaunchKernelGGL((qkv_rope_append_fast_kernel<__bf16, 4>), grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K, (const __bf16 *)norm_w, norm_eps);
+            else hipLaunchKernelGGL((qkv_rope_append_fast_kernel<_Float16, 4>), grid, block, 0, st, P, (const _Float16 *)X, (const _Float16 *)W, K, (const _Float16 *)norm_w, norm_eps);
+        }
+        NSA_LAUNCH_CHECK("qkv_rope_append(fast)");
+        return NSA_OK;
+    }
     if (dtype == NSA_DT_F32) hipLaunchKernelGGL(qkv_rope_append_kernel<float>, grid, block, 0, st, P, (const float *)X, (const float *)W, K, (const float *)norm_w, norm_eps);
     else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(qkv_rope_append_kernel<__bf16>, grid, block, 0, st, P, (const __bf16 *)X, (const __bf16 *)W, K, (const __bf16 *)norm_w, norm_eps);
     else hipLaunchKernelGGL(qkv_rope_append_kernel<_Float16>, grid, block, 0, st, P, (const _Float16 *)X, (const _Float16 *)W, K, (const _Float16 *)norm_w, norm_eps);
