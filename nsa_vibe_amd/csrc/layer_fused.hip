@@ -627,6 +627,46 @@ __global__ __launch_bounds__(256, 2) void qkv_rope_append_kernel(RopeAppendParam
     }
 }
 
+// destination and rotation of the column pair starting at `col` of a decode-step projection row (S = 1): rope_store_pair's cases with the
+// position-only part (powf + sincosf) separated, so that a kernel can evaluate it while its loads are in flight
+template <typename T>
+struct RopeDest {
+    float sn, cs;
+    bool rot;
+    T *dst;           // row b = 0
+    int64_t dst_row;  // elements between consecutive rows b
+    __device__ __forceinline__ void init(const RopeAppendParams &P, int col) {
+        const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
+        const float pos = (float)P.t0;
+        sn = 0.f;
+        cs = 1.f;
+        if (col < NQ) {
+            rot = true;
+            rope_sincos<T>(col >> 1, NQ, pos, P.rope_base, P.inv_scale, sn, cs);
+            dst = (T *)P.Q_out + col;
+            dst_row = NQ;
+            return;
+        }
+        int c = col - NQ;
+        const int pairw = GK + GV;
+        const int sp = min(c / pairw, 2);
+        c -= sp * pairw;
+        const bool isv = c >= GK;
+        if (isv) c -= GK;
+        const int D = isv ? P.Dv : P.Dk;
+        const int g = c / D, dc = c - g * D;
+        rot = !isv && sp < 2;
+        if (rot) rope_sincos<T>(dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, sn, cs);
+        dst = (T *)P.cache[2 * sp + (isv ? 1 : 0)] + ((int64_t)g * P.S_max + P.t0) * D + dc;
+        dst_row = (int64_t)P.G * P.S_max * D;
+    }
+    __device__ __forceinline__ void store(int b, float x0, float x1) const {
+        if (rot) rope_rotate<T>(x0, x1, sn, cs, x0, x1);
+        dst[b * dst_row] = Elt<T>::from_f(x0);
+        dst[b * dst_row + 1] = Elt<T>::from_f(x1);
+    }
+};
+
 // latency form of qkv_rope_append_kernel for 1-2 rows, K <= 512 NC (see linear_small_fast_kernel): every load out first, the pair's
 // rotation (powf + sincosf, ~1 us of arithmetic that depends on the position only) evaluated while they are in flight
 template <typename T, int NC>
@@ -653,32 +693,8 @@ __global__ __launch_bounds__(256, 2) void qkv_rope_append_fast_kernel(RopeAppend
         for (int r = 0; r < 2; ++r)
             if (r < M) xr[r][c] = *(const u32x4 *)(X + (int64_t)r * K + kc);
     }
-    // destination and rotation of this wave's column pair (rope_store_pair's cases)
-    const int col = 2 * pair;
-    const float pos = (float)P.t0;
-    float sn = 0.f, cs = 1.f;
-    bool rot;
-    T *dst;
-    int64_t dst_row;  // elements between the rows b of the destination
-    if (col < NQ) {
-        rot = true;
-        rope_sincos<T>(col >> 1, NQ, pos, P.rope_base, P.inv_scale, sn, cs);
-        dst = (T *)P.Q_out + col;
-        dst_row = NQ;
-    } else {
-        int c = col - NQ;
-        const int pairw = GK + GV;
-        const int sp = c / pairw;
-        c -= sp * pairw;
-        const bool isv = c >= GK;
-        if (isv) c -= GK;
-        const int D = isv ? P.Dv : P.Dk;
-        const int g = c / D, dc = c - g * D;
-        rot = !isv && sp < 2;
-        if (rot) rope_sincos<T>(dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, sn, cs);
-        dst = (T *)P.cache[2 * sp + (isv ? 1 : 0)] + ((int64_t)g * P.S_max + P.t0) * D + dc;
-        dst_row = (int64_t)P.G * P.S_max * D;
-    }
+    RopeDest<T> rd;  // destination and rotation of this wave's column pair, evaluated under the loads
+    rd.init(P, 2 * pair);
     float rms[2] = {1.f, 1.f};
     if (norm_w) {
 #pragma unroll
@@ -724,12 +740,8 @@ __global__ __launch_bounds__(256, 2) void qkv_rope_append_fast_kernel(RopeAppend
 #pragma unroll
     for (int r = 0; r < 2; ++r)
         if (r < M) {
-            float x0 = rnd<T>(wave_sum(a0[r])), x1 = rnd<T>(wave_sum(a1[r]));  // the projection output in the activation dtype
-            if (rot) rope_rotate<T>(x0, x1, sn, cs, x0, x1);
-            if (lane == 0) {
-                dst[r * dst_row] = Elt<T>::from_f(x0);
-                dst[r * dst_row + 1] = Elt<T>::from_f(x1);
-            }
+            const float x0 = rnd<T>(wave_sum(a0[r])), x1 = rnd<T>(wave_sum(a1[r]));  // the projection output in the activation dtype
+            if (lane == 0) rd.store(r, x0, x1);
         }
 }
 
@@ -759,6 +771,11 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P,
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const T *wrow = W + (int64_t)min(n0 + rho, N - 1) * K + 8 * q;  // the last column tile may be partial: clamp, store guarded
+    [[maybe_unused]] RopeDest<T> rd[2];  // ROPE (P.S == 1): the two column pairs of this thread's epilogue, their rotations evaluated under the loads
+    if constexpr (ROPE) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) rd[p].init(P, min(n0 + 4 * (int)(threadIdx.x >> 6) + 2 * p, N - 2));
+    }
     if constexpr (MIX) {
         const int kpg = K / mx.G;
         const int nmt = min(4, (M - m0 + 15) >> 4);  // 16-row tiles that hold a row (the plain form computes clamped duplicates instead)
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P,
     if (ROPE) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            if (n0 + 4 * nq + 2 * p < N) rope_store_pair<T>(P, m, 0, n0 + 4 * nq + 2 * p, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
+            if (n0 + 4 * nq + 2 * p < N) rd[p].store(m, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
