@@ -233,6 +233,39 @@ def test_linear_small(dtype, M):
     assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,epi", [(1, 768, 768, 0), (2, 3072, 768, 1), (1, 768, 3072, 2), (2, 768, 3072, 2), (1, 512, 4096, 0),
+                                       (2, 50257, 768, 0), (1, 4100, 1000, 1), (2, 40, 8, 2)])
+def test_linear_small_latency_forms_equal_the_generic_kernels(dtype, M, N, K, epi):
+    """1-2 rows of a 16-bit dtype with 16-byte aligned operands take the latency forms (every load issued before the first use); an A whose
+    rows start 2 bytes off a 16-byte boundary takes the generic chunk loops: same arithmetic in the same order, the same bits, with every
+    epilogue (none / silu / + residual) and on the 4-column form of the LM head"""
+    from nsa_vibe_amd import _lib
+    from nsa_vibe_amd.selection_scorer import _DT, _stream
+
+    torch.manual_seed(M * 1000 + K)
+    W = (torch.randn(N, K, device="cuda") / (K ** 0.5)).to(dtype)
+    buf = torch.randn(M * K + 8, device="cuda").to(dtype)
+    A_al = buf[:M * K].view(M, K)
+    A_off = torch.empty(M * K + 8, device="cuda", dtype=dtype)
+    A_off[1:1 + M * K] = buf[:M * K]
+    res = torch.randn(M, N, device="cuda").to(dtype) if epi == 2 else None
+    outs = []
+    for A in (A_al, A_off[1:1 + M * K]):
+        out = torch.empty(M, N, device="cuda", dtype=dtype)
+        _lib.check(_lib.lib().nsa_linear_small(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, _DT[dtype], epi,
+                                               res.data_ptr() if res is not None else None, _stream(W.device)), "linear")
+        outs.append(out)
+    assert A_al.data_ptr() % 16 == 0 and A_off[1:].data_ptr() % 16 != 0
+    assert torch.equal(outs[0], outs[1])
+    ref = A_al.float() @ W.float().t()
+    if epi == 1:
+        ref = torch.nn.functional.silu(ref)
+    elif epi == 2:
+        ref = ref + res.float()
+    assert (outs[0].float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
 def test_batched_decode_native_matches_eager(monkeypatch):
     """B = 24 rows per step: the MFMA projection kernels and the non-split / split branch routes of the one-call decode step"""
     from nsa_vibe_amd.nsa_attention import NSAAttention
