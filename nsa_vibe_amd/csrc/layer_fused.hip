@@ -992,10 +992,61 @@ __global__ __launch_bounds__(64) void cmp_pool_kernel(CmpPoolParams P) {
     }
 }
 
+// the same with the l rotations of a pair spread over the threads of a 256-thread block (the 64-thread form walks them one after the other:
+// l x (powf + sincosf) in a row, 24 us for the ONE token a decode step emits): rotated keys and raw values go to LDS, then one thread per
+// column sums them in the original order i = 0 .. l-1 -- the same fp32 additions, the same bits.  (Sharing a rotation between the (b, g)
+// pairs of a block -- it depends on position and pair only -- was tried: fewer, serial blocks, 30 -> 45 us at 4k x 8.)
+template <typename T>
+__global__ __launch_bounds__(256) void cmp_pool_wide_kernel(CmpPoolParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *rk = (float *)smem;    // [l][Dk] rotated raw keys
+    float *rv = rk + P.l * P.Dk;  // [l][Dv] raw values
+    const int nj = P.j1 - P.j0;
+    const int j = P.j0 + (int)(blockIdx.x % nj);
+    const int bg = (int)(blockIdx.x / nj);
+    const T *Kr = (const T *)P.K_raw + (int64_t)bg * P.S_max * P.Dk;
+    const T *Vr = (const T *)P.V_raw + (int64_t)bg * P.S_max * P.Dv;
+    T *Kc = (T *)P.K_cmp + ((int64_t)bg * P.n_cmp_max + j) * P.Dk;
+    T *Vc = (T *)P.V_cmp + ((int64_t)bg * P.n_cmp_max + j) * P.Dv;
+    const int r0 = j * P.d, hp = P.Dk / 2;
+    for (int it = threadIdx.x; it < P.l * hp; it += 256) {
+        const int i = it / hp, pp = it - i * hp;
+        const T *src = Kr + (int64_t)(r0 + i) * P.Dk + 2 * pp;
+        float x0, x1;
+        rope_pair<T>(Elt<T>::to_f(src[0]), Elt<T>::to_f(src[1]), pp, P.Dk, (float)(r0 + i), P.rope_base, P.inv_scale, x0, x1);
+        rk[i * P.Dk + 2 * pp] = x0;
+        rk[i * P.Dk + 2 * pp + 1] = x1;
+    }
+    for (int it = threadIdx.x; it < P.l * P.Dv; it += 256) {
+        const int i = it / P.Dv, c = it - i * P.Dv;
+        rv[it] = Elt<T>::to_f(Vr[(int64_t)(r0 + i) * P.Dv + c]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < P.Dk + P.Dv; c += 256) {
+        const bool isv = c >= P.Dk;
+        const float *col = isv ? rv + (c - P.Dk) : rk + c;
+        const int stride = isv ? P.Dv : P.Dk;
+        float a = 0.f;
+        for (int i = 0; i < P.l; ++i) a += col[i * stride];
+        if (isv) Vc[c - P.Dk] = Elt<T>::from_f(a / (float)P.l);
+        else Kc[c] = Elt<T>::from_f(a / (float)P.l);
+    }
+}
+
 int launch_cmp_pool(const CmpPoolParams &P, int dtype, hipStream_t st) {
     const int64_t nblk = (int64_t)P.nbg * (P.j1 - P.j0);
     if (nblk <= 0) return NSA_OK;
     NSA_CHECK_ARG(nblk < ((int64_t)1 << 31), "cmp_pool: too many blocks");
+    const size_t lds = sizeof(float) * (size_t)P.l * (size_t)(P.Dk + P.Dv);
+    // (a prefill pools thousands of tokens: there the 64-thread form's many small blocks fill the chip better; the wide form is for the few
+    // tokens of a decode step, where the length of one block's chain is the kernel's time)
+    if (lds <= 48 * 1024 && P.Dk % 2 == 0 && nblk <= 1024) {
+        if (dtype == NSA_DT_F32) hipLaunchKernelGGL(cmp_pool_wide_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, st, P);
+        else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(cmp_pool_wide_kernel<__bf16>, dim3((unsigned)nblk), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL(cmp_pool_wide_kernel<_Float16>, dim3((unsigned)nblk), dim3(256), lds, st, P);
+        NSA_LAUNCH_CHECK("cmp_pool(wide)");
+        return NSA_OK;
+    }
     if (dtype == NSA_DT_F32) hipLaunchKernelGGL(cmp_pool_kernel<float>, dim3((unsigned)nblk), dim3(64), 0, st, P);
     else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(cmp_pool_kernel<__bf16>, dim3((unsigned)nblk), dim3(64), 0, st, P);
     else hipLaunchKernelGGL(cmp_pool_kernel<_Float16>, dim3((unsigned)nblk), dim3(64), 0, st, P);
