@@ -447,24 +447,27 @@ __global__ __launch_bounds__(256) void rope_cache_append_kernel(RopeAppendParams
         }
     }
     const float inv_freq = ri >= 0 ? powf(P.rope_base, (-2.0f * (float)ri) / (float)rD) : 0.f;
-    const int64_t ntok = (int64_t)P.B * P.S;
-    for (int64_t row = blockIdx.y; row < ntok; row += gridDim.y) {
-        const int b = (int)(row / P.S), s = (int)(row - (int64_t)b * P.S);
-        const T *src = (const T *)P.proj + row * NT + col;
-        float x0 = Elt<T>::to_f(src[0]), x1 = Elt<T>::to_f(src[1]);
+    // positions outside, sequences inside: the rotation (sincosf: most of this kernel's arithmetic) depends on the position only
+    for (int s = blockIdx.y; s < P.S; s += gridDim.y) {
+        float sn = 0.f, cs = 1.f;
         if (ri >= 0) {
             const float ang = ((float)(P.t0 + s) * P.inv_scale) * inv_freq;
-            float sn, cs;
             sincosf(ang, &sn, &cs);
             sn = rnd<T>(sn);
             cs = rnd<T>(cs);
-            const float r0 = rnd<T>(rnd<T>(x0 * cs) - rnd<T>(x1 * sn));
-            x1 = rnd<T>(rnd<T>(x0 * sn) + rnd<T>(x1 * cs));
-            x0 = r0;
         }
-        T *d = dst + b * sb + s * ss;
-        d[0] = Elt<T>::from_f(x0);
-        d[1] = Elt<T>::from_f(x1);
+        for (int b = blockIdx.z; b < P.B; b += gridDim.z) {
+            const T *src = (const T *)P.proj + ((int64_t)b * P.S + s) * NT + col;
+            float x0 = Elt<T>::to_f(src[0]), x1 = Elt<T>::to_f(src[1]);
+            if (ri >= 0) {
+                const float r0 = rnd<T>(rnd<T>(x0 * cs) - rnd<T>(x1 * sn));
+                x1 = rnd<T>(rnd<T>(x0 * sn) + rnd<T>(x1 * cs));
+                x0 = r0;
+            }
+            T *d = dst + b * sb + s * ss;
+            d[0] = Elt<T>::from_f(x0);
+            d[1] = Elt<T>::from_f(x1);
+        }
     }
 }
 
@@ -472,7 +475,10 @@ int launch_rope_cache_append(const RopeAppendParams &P, int dtype, hipStream_t s
     const int NT = P.G * P.h * P.Dk + 3 * P.G * P.Dk + 3 * P.G * P.Dv;
     const int64_t ntok = (int64_t)P.B * P.S;
     if (ntok == 0) return NSA_OK;
-    const dim3 grid((unsigned)((NT / 2 + 255) / 256), (unsigned)std::min<int64_t>(ntok, 2048));
+    // (rows of positions x slices of the batch: about 2048 of them; a thread shares one rotation between the sequences of its slice)
+    const unsigned gy = (unsigned)std::min<int64_t>(P.S, 2048);
+    const unsigned gz = (unsigned)std::max<int64_t>(1, std::min<int64_t>(P.B, 2048 / gy));
+    const dim3 grid((unsigned)((NT / 2 + 255) / 256), gy, gz);
     if (dtype == NSA_DT_F32) hipLaunchKernelGGL(rope_cache_append_kernel<float>, grid, dim3(256), 0, st, P);
     else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL(rope_cache_append_kernel<__bf16>, grid, dim3(256), 0, st, P);
     else hipLaunchKernelGGL(rope_cache_append_kernel<_Float16>, grid, dim3(256), 0, st, P);
@@ -975,10 +981,32 @@ __global__ __launch_bounds__(64) void cmp_pool_kernel(CmpPoolParams P) {
     const int r0 = j * P.d;
     for (int p = threadIdx.x; p < P.Dk / 2; p += 64) {
         float a0 = 0.f, a1 = 0.f;
+        const float inv_freq = powf(P.rope_base, (-2.0f * (float)p) / (float)P.Dk);  // (rope_sincos's value, once per pair instead of per token)
+        if (P.l <= 32) {
+            // the l loads of the pair first (the loop below waits for each token's load behind the previous token's sincosf: a block was
+            // as long as l dependent memory round trips)
+            float xa[32], xb[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const T *src = Kr + (int64_t)(r0 + min(i, P.l - 1)) * P.Dk + 2 * p;
+                xa[i] = Elt<T>::to_f(src[0]);
+                xb[i] = Elt<T>::to_f(src[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i < P.l) {
+                    float x0, x1, sn, cs;
+                    sincosf(((float)(r0 + i) * P.inv_scale) * inv_freq, &sn, &cs);
+                    rope_rotate<T>(xa[i], xb[i], rnd<T>(sn), rnd<T>(cs), x0, x1);
+                    a0 += x0;
+                    a1 += x1;
+                }
+        } else
         for (int i = 0; i < P.l; ++i) {
             const T *src = Kr + (int64_t)(r0 + i) * P.Dk + 2 * p;
-            float x0, x1;
-            rope_pair<T>(Elt<T>::to_f(src[0]), Elt<T>::to_f(src[1]), p, P.Dk, (float)(r0 + i), P.rope_base, P.inv_scale, x0, x1);
+            float x0, x1, sn, cs;
+            sincosf(((float)(r0 + i) * P.inv_scale) * inv_freq, &sn, &cs);
+            rope_rotate<T>(Elt<T>::to_f(src[0]), Elt<T>::to_f(src[1]), rnd<T>(sn), rnd<T>(cs), x0, x1);
             a0 += x0;
             a1 += x1;
         }
