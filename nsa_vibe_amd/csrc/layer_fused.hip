@@ -1318,6 +1318,35 @@ __global__ __launch_bounds__(256) void gate_combine_kernel(GateCombineParams P) 
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= P.R) return;
     float pr[3];
+    if constexpr (sizeof(T) == 2) {
+        // the m7c geometry with 16-byte aligned branch outputs: every load of the row -- Q, the gate weights AND the three branch outputs (one
+        // 16-byte piece per lane instead of six 2-byte loads) -- is out before the gate arithmetic starts
+        const int ne = P.h * P.Dv;
+        if (P.Dk == 64 && P.Hd <= 32 && P.h <= 8 && ne % 8 == 0 && ne <= 512 &&
+            (((uintptr_t)P.O_cmp | (uintptr_t)P.O_sel | (uintptr_t)P.O_win | (uintptr_t)P.O_out) % 16 == 0)) {
+            GateFast<T> gf;
+            gf.load((const T *)P.Q + row * P.h * 64, P.h, P.Hd, P.w1, P.b1, P.w2, P.b2);
+            const int64_t base = row * ne;
+            const bool mine = lane * 8 < ne;
+            const int off = mine ? lane * 8 : 0;
+            const u32x4 rc = *(const u32x4 *)((const T *)P.O_cmp + base + off), rs = *(const u32x4 *)((const T *)P.O_sel + base + off),
+                        rw = *(const u32x4 *)((const T *)P.O_win + base + off);
+            gf.compute(P.h, P.Hd, P.tau, sqp[wave], pr);
+            if (P.gates_out && lane < 3) P.gates_out[row * 3 + lane] = lane == 0 ? pr[0] : (lane == 1 ? pr[1] : pr[2]);
+            if (mine) {
+                float oc[8], os[8], ow[8];
+                raw8<T>(rc, oc);
+                raw8<T>(rs, os);
+                raw8<T>(rw, ow);
+                u32x4 outv;
+                T *ov = (T *)&outv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = Elt<T>::from_f(mix3<T>(pr, oc[j], os[j], ow[j]));
+                *(u32x4 *)((T *)P.O_out + base + off) = outv;
+            }
+            return;
+        }
+    }
     if (P.Dk == 64 && P.Hd <= 32 && P.h <= 8) {
         GateFast<T> gf;
         gf.load((const T *)P.Q + row * P.h * 64, P.h, P.Hd, P.w1, P.b1, P.w2, P.b2);
