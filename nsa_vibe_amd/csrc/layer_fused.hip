@@ -762,17 +762,30 @@ struct LinearMixArgs {
     const float *gates;
     int G;
 };
-template <typename T, bool ROPE, bool MIX = false>
-__global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
-                                                          T *__restrict__ out, int M, int N, int K, int epi, const T *__restrict__ res,
-                                                          LinearMixArgs mx) {
+// NWV = waves of a workgroup that split the K axis: 4, or 8 for long rows (K >= 2048: fc2 of the MLP) -- a wave's k-steps go out in
+// rounds of 6, each round a memory round trip, so K = 3072 on 4 waves was four of them in a row (15.5 us at 32 rows, 8.5 for fc1)
+template <typename T, bool ROPE, bool MIX = false, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, 2) void linear_mfma_kernel(RopeAppendParams P, const T *__restrict__ X, const T *__restrict__ W,
+                                                               T *__restrict__ out, int M, int N, int K, int epi, const T *__restrict__ res,
+                                                               LinearMixArgs mx) {
+    static_assert(NWV == 4 || (NWV == 8 && !ROPE && !MIX), "eight waves: the plain projection only");
     using MT_ = MfmaT<T>;
     using x8 = typename MT_::x8;
-    __shared__ float part[4][16][65];
+    __shared__ float part[NWV][16][65];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), rho = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
-    const int ksteps = K / 32, per = (ksteps + 3) / 4;
+    const int ksteps = K / 32, per = (ksteps + NWV - 1) / NWV;
     const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+    // the residual of this thread's outputs, fetched now: in the epilogue it would be one more dependent memory round trip
+    constexpr int CPT = 16 / NWV;  // columns per thread of the epilogue
+    [[maybe_unused]] float resv[CPT];
+    if constexpr (!ROPE) {
+        if (epi == 2) {
+            const int m = min(m0 + (int)(threadIdx.x & 63), M - 1), nq = (int)(threadIdx.x >> 6);
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) resv[r] = Elt<T>::to_f(res[(int64_t)m * N + min(n0 + CPT * nq + r, N - 1)]);
+        }
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -824,25 +837,26 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P,
         };
         if (nmt == 1) run(std::integral_constant<int, 6>{});
         else run(std::integral_constant<int, 2>{});
-    } else
-    for (int sb = s0; sb < s1; sb += 6) {  // 6 k-steps (30 loads) in flight per round
-        x8 wf[6], xf[6][4];
+    } else {
+        const int nmt = min(4, (M - m0 + 15) >> 4);  // 16-row tiles that hold a row: the others are neither fetched nor multiplied
+        for (int sb = s0; sb < s1; sb += 6) {  // 6 k-steps (up to 30 loads) in flight per round
+            x8 wf[6], xf[6][4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int s = min(sb + i, s1 - 1);
-            wf[i] = *(const x8 *)(wrow + 32 * s);
+            for (int i = 0; i < 6; ++i) {
+                const int s = min(sb + i, s1 - 1);
+                wf[i] = *(const x8 *)(wrow + 32 * s);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = min(m0 + 16 * mt + rho, M - 1);
-                xf[i][mt] = *(const x8 *)(X + (int64_t)m * K + 32 * s + 8 * q);
+                for (int mt = 0; mt < 4; ++mt)
+                    if (mt < nmt) xf[i][mt] = *(const x8 *)(X + (int64_t)min(m0 + 16 * mt + rho, M - 1) * K + 32 * s + 8 * q);
             }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (sb + i < s1) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        if (mt < nmt) acc[mt] = MT_::mma(wf[i], xf[i][mt], acc[mt]);
+                }
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (sb + i < s1) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = MT_::mma(wf[i], xf[i][mt], acc[mt]);
-            }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -850,11 +864,12 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P,
         for (int r = 0; r < 4; ++r) part[wave][4 * q + r][16 * mt + rho] = acc[mt][r];
     __syncthreads();
     const int m = m0 + (threadIdx.x & 63), nq = threadIdx.x >> 6;
-    float v[4];
+    float v[CPT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = 4 * nq + r, mm = threadIdx.x & 63;
+    for (int r = 0; r < CPT; ++r) {
+        const int n = CPT * nq + r, mm = threadIdx.x & 63;
         v[r] = (part[0][n][mm] + part[1][n][mm]) + (part[2][n][mm] + part[3][n][mm]);
+        if constexpr (NWV == 8) v[r] += (part[4][n][mm] + part[5][n][mm]) + (part[6][n][mm] + part[7][n][mm]);
     }
     if (m >= M) return;
     if (ROPE) {
@@ -863,10 +878,13 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(RopeAppendParams P,
             if (n0 + 4 * nq + 2 * p < N) rd[p].store(m, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (n0 + 4 * nq + r >= N) break;
-            const int64_t idx = (int64_t)m * N + n0 + 4 * nq + r;
-            out[idx] = Elt<T>::from_f(linear_epilogue<T>(v[r], epi, res, idx));
+        for (int r = 0; r < CPT; ++r) {
+            if (n0 + CPT * nq + r >= N) break;
+            const int64_t idx = (int64_t)m * N + n0 + CPT * nq + r;
+            float y = rnd<T>(v[r]);  // linear_epilogue's steps, the residual from the registers
+            if (epi == 1) y = rnd<T>(y / (1.f + expf(-y)));
+            else if (epi == 2) y = y + resv[r];
+            out[idx] = Elt<T>::from_f(y);
         }
     }
 }
@@ -880,7 +898,10 @@ int launch_linear_small_epi(const void *A, const void *W, void *out, int M, int 
     if (linear_mfma_ok(dtype, M, N, K, A, W)) {
         RopeAppendParams P{};
         const dim3 g2((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
-        if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res, LinearMixArgs{});
+        if (K >= 2048) {
+            if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false, false, 8>), g2, dim3(512), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res, LinearMixArgs{});
+            else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false, false, 8>), g2, dim3(512), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res, LinearMixArgs{});
+        } else if (dtype == NSA_DT_BF16) hipLaunchKernelGGL((linear_mfma_kernel<__bf16, false>), g2, dim3(256), 0, st, P, (const __bf16 *)A, (const __bf16 *)W, (__bf16 *)out, M, N, K, epi, (const __bf16 *)res, LinearMixArgs{});
         else hipLaunchKernelGGL((linear_mfma_kernel<_Float16, false>), g2, dim3(256), 0, st, P, (const _Float16 *)A, (const _Float16 *)W, (_Float16 *)out, M, N, K, epi, (const _Float16 *)res, LinearMixArgs{});
         NSA_LAUNCH_CHECK("linear_small(mfma)");
         return NSA_OK;
