@@ -641,14 +641,15 @@ struct RopeDest {
     bool rot;
     T *dst;           // row b = 0
     int64_t dst_row;  // elements between consecutive rows b
-    __device__ __forceinline__ void init(const RopeAppendParams &P, int col) {
+    // with_rotation = false: destination only (sn / cs come from elsewhere, e.g. from a thread of the workgroup that evaluated them once)
+    __device__ __forceinline__ void init(const RopeAppendParams &P, int col, bool with_rotation = true) {
         const int NQ = P.G * P.h * P.Dk, GK = P.G * P.Dk, GV = P.G * P.Dv;
         const float pos = (float)P.t0;
         sn = 0.f;
         cs = 1.f;
         if (col < NQ) {
             rot = true;
-            rope_sincos<T>(col >> 1, NQ, pos, P.rope_base, P.inv_scale, sn, cs);
+            if (with_rotation) rope_sincos<T>(col >> 1, NQ, pos, P.rope_base, P.inv_scale, sn, cs);
             dst = (T *)P.Q_out + col;
             dst_row = NQ;
             return;
@@ -662,7 +663,7 @@ struct RopeDest {
         const int D = isv ? P.Dv : P.Dk;
         const int g = c / D, dc = c - g * D;
         rot = !isv && sp < 2;
-        if (rot) rope_sincos<T>(dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, sn, cs);
+        if (rot && with_rotation) rope_sincos<T>(dc >> 1, P.Dk, pos, P.rope_base, P.inv_scale, sn, cs);
         dst = (T *)P.cache[2 * sp + (isv ? 1 : 0)] + ((int64_t)g * P.S_max + P.t0) * D + dc;
         dst_row = (int64_t)P.G * P.S_max * D;
     }
@@ -790,10 +791,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_mfma_kernel(RopeAppendPara
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const T *wrow = W + (int64_t)min(n0 + rho, N - 1) * K + 8 * q;  // the last column tile may be partial: clamp, store guarded
-    [[maybe_unused]] RopeDest<T> rd[2];  // ROPE (P.S == 1): the two column pairs of this thread's epilogue, their rotations evaluated under the loads
+    // ROPE (P.S == 1): the rotations of the workgroup's 8 column pairs depend on the position only -- threads 0..7 evaluate one each (powf +
+    // sincosf) while the loads are in flight and pass it through LDS; every thread then needs only the destinations of its two pairs
+    [[maybe_unused]] RopeDest<T> rd[2];
+    __shared__ float rsc[8][2];
     if constexpr (ROPE) {
+        if (threadIdx.x < 8) {
+            RopeDest<T> one;
+            one.init(P, min(n0 + 2 * (int)threadIdx.x, N - 2));
+            rsc[threadIdx.x][0] = one.sn;
+            rsc[threadIdx.x][1] = one.cs;
+        }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) rd[p].init(P, min(n0 + 4 * (int)(threadIdx.x >> 6) + 2 * p, N - 2));
+        for (int p = 0; p < 2; ++p) rd[p].init(P, min(n0 + 4 * (int)(threadIdx.x >> 6) + 2 * p, N - 2), false);
     }
     if constexpr (MIX) {
         const int kpg = K / mx.G;
@@ -875,7 +885,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void linear_mfma_kernel(RopeAppendPara
     if (ROPE) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            if (n0 + 4 * nq + 2 * p < N) rd[p].store(m, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
+            if (n0 + 4 * nq + 2 * p < N) {
+                rd[p].sn = rsc[2 * nq + p][0];  // (written before the barrier above)
+                rd[p].cs = rsc[2 * nq + p][1];
+                rd[p].store(m, rnd<T>(v[2 * p]), rnd<T>(v[2 * p + 1]));
+            }
     } else {
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {

@@ -135,6 +135,12 @@ class GateMLP(nn.Module):
         return torch.where(peaked.unsqueeze(-1), one_hot, p)
 
 
+def _set_plain(module, name, value):
+    """attribute of a module that is neither parameter, buffer nor submodule, set without nn.Module.__setattr__ (whose isinstance checks
+    against Parameter cost tens of microseconds per assignment -- more host time than a decode step's three launches)"""
+    object.__setattr__(module, name, value)
+
+
 def _gate_probs_fn(q_pooled, w1, b1, w2, b2, tau):
     """functional form of GateMLP.forward (used to take the gate MLP's gradient in _GateCombineFn.backward)"""
     g = F.linear(F.silu(F.linear(q_pooled, w1, b1)), w2, b2) / max(tau, 1e-6)
@@ -224,7 +230,7 @@ class _GateCombineFn(torch.autograd.Function):
                                       gates.data_ptr(), B * S * G, _stream(dev)), "nsa_gate_combine")
         ctx.save_for_backward(Qc, Oc, Os, Ow, gates, w1, b1, w2, b2)
         ctx.module = module
-        module._last_gates = gates
+        _set_plain(module, "_last_gates", gates)
         return O
 
     @staticmethod
@@ -342,9 +348,14 @@ class NSAAttention(nn.Module):
 
     def _layer_desc(self):
         """(nsa_layer_desc, fused W_qkv) -- rebuilt when a parameter was modified or moved (tensor version counters)"""
-        ps = [getattr(self, n).weight for n in self._QKV] + [self.out.weight, self.gate.fc1.weight, self.gate.fc1.bias,
-                                                               *self.gate.fc2_params()]
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        # (the parameters through the modules' own dictionaries: nn.Module.__getattr__ on thirteen dotted paths was the largest item of a
+        # decode step's host time)
+        mods = self._modules
+        gate = mods["gate"]
+        fc1 = gate._modules["fc1"]._parameters
+        ps = [mods[n]._parameters["weight"] for n in self._QKV] + [mods["out"]._parameters["weight"], fc1["weight"], fc1["bias"],
+                                                                    *gate.fc2_params()]
+        key = tuple([(p.data_ptr(), p._version) for p in ps])
         if getattr(self, "_desc_key", None) != key or self._desc_keep[0].dtype != ps[0].dtype:
             W_qkv = torch.cat([p.detach() for p in ps[:7]], dim=0).contiguous()
             keep = [W_qkv] + [p.detach().contiguous() for p in ps[7:]]
@@ -355,7 +366,9 @@ class NSAAttention(nn.Module):
             d.rope_base, d.rope_scale, d.gate_tau = 10000.0, self.rope_scale, float(self.gate_temp)
             d.W_qkv, d.W_out = keep[0].data_ptr(), keep[1].data_ptr()
             d.gate_w1, d.gate_b1, d.gate_w2, d.gate_b2 = (k.data_ptr() for k in keep[2:])
-            self._desc_key, self._desc, self._desc_keep = key, d, keep
+            _set_plain(self, "_desc_key", key)
+            _set_plain(self, "_desc", d)
+            _set_plain(self, "_desc_keep", keep)
         return self._desc, self._desc_keep[0]
 
     @staticmethod
@@ -383,7 +396,7 @@ class NSAAttention(nn.Module):
     def _combine(self, Q, O_cmp, O_sel, O_win):
         B, S = Q.shape[:2]
         gates = self.gate(Q.mean(dim=3), tau=self.gate_temp)  # [B,S,G,3]
-        self._last_gates = gates
+        _set_plain(self, "_last_gates", gates)
         O = gates[..., 0:1].unsqueeze(3) * O_cmp + gates[..., 1:2].unsqueeze(3) * O_sel + gates[..., 2:3].unsqueeze(3) * O_win
         return self.out(O.reshape(B, S, self.n_heads * self.d_v))
 
@@ -454,7 +467,7 @@ class NSAAttention(nn.Module):
             O_sel = parity(Qc, kv.K_sel, kv.V_sel, ranges)
         else:
             O_sel = selection_attention_hip(Qc, kv.K_sel, kv.V_sel, ranges, scale=scale)
-        self._last_ranges = ranges
+        _set_plain(self, "_last_ranges", ranges)
         # ---- compressed + sliding branches (HIP band kernel)
         O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, scale=scale)
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S], kv._V_win[:, :, :S], self.w, scale=scale)
@@ -490,7 +503,8 @@ class NSAAttention(nn.Module):
         _lib.check(rc, "nsa_layer_prefill")
         kv.t = S
         kv.n_cmp = 0 if S < self.l else (S - self.l) // self.d + 1
-        self._last_ranges, self._last_gates = ranges, gates
+        _set_plain(self, "_last_ranges", ranges)
+        _set_plain(self, "_last_gates", gates)
         return O if mix_only else self.out(O), kv
 
     def _prefill_train_native(self, x: torch.Tensor, kv: NSA_KV):
@@ -507,7 +521,7 @@ class NSAAttention(nn.Module):
         scale = 1.0 / math.sqrt(self.d_k)
         with torch.no_grad():  # the selection itself is not differentiable (top-n indices)
             ranges = _scores_and_ranges(Q.detach(), kv.K_cmp, meta, self.n_sel, self.selector, S, scale)
-        self._last_ranges = ranges
+        _set_plain(self, "_last_ranges", ranges)
         O_sel = selection_attention_hip(Q, K_sel, V_sel, ranges, scale=scale)
         O_cmp = batched_causal_attention_compressed(Q, K_cmp, V_cmp, self.l, self.d, scale=scale)
         O_win = sliding_window_attention(Q, K_win, V_win, self.w, scale=scale)
@@ -546,7 +560,8 @@ class NSAAttention(nn.Module):
         _lib.check(rc, "nsa_layer_decode_step")
         kv.t, kv.n_cmp = S_raw, num_cmp
         kv.append_reads(num_cmp, S_raw)
-        self._last_ranges, self._last_gates = ranges, gates
+        _set_plain(self, "_last_ranges", ranges)
+        _set_plain(self, "_last_gates", gates)
         return y, kv
 
     def _decode(self, x: torch.Tensor, kv: NSA_KV, one_call: bool = True):
@@ -574,7 +589,7 @@ class NSAAttention(nn.Module):
         O_sel, ranges = selection_decode_step(Qc, kv.K_cmp, kv.K_sel, kv.V_sel, kv.meta, self.n_sel, t, scale=scale)
         if self._force_parity:  # the reference's decode gather route (_sdpa_over_ranges, nsa_attention.py:830)
             O_sel = selection_attention_head_causal_parity(Qc, kv.K_sel, kv.V_sel, ranges.unsqueeze(1))
-        self._last_ranges = ranges
+        _set_plain(self, "_last_ranges", ranges)
         # the query sits at position t: window = the last w cached tokens, compressed = every token emitted so far
         O_win = sliding_window_attention(Qc, kv._K_win[:, :, :S_raw], kv._V_win[:, :, :S_raw], self.w, t0=t, scale=scale)
         O_cmp = batched_causal_attention_compressed(Qc, kv.K_cmp, kv.V_cmp, self.l, self.d, t0=t, scale=scale)

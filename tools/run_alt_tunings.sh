@@ -16,3 +16,8 @@ run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0
 run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0 NSA_HIP_SEL_KSPLIT_T1=200 NSA_HIP_SEL_KSPLIT_T2=900
 run NSA_HIP_SEL_KSPLIT=1 NSA_HIP_SEL_FLAT=0 NSA_HIP_SEL_KSPLIT_T1=0 NSA_HIP_SEL_KSPLIT_T2=0
 run NSA_HIP_SCORES_SELECT=1 NSA_HIP_DECODE_WIDE=1
+# the layer decode step with the band branches as their own launch / on the step's launch with the finish kernel / with the mix in the
+# projection at every batch, the last two with the step forced into a team of workgroups and into the one-pass form
+run NSA_HIP_DECODE_BAND=0
+run NSA_HIP_DECODE_BAND=1 NSA_HIP_DECODE_SPLIT=2
+run NSA_HIP_DECODE_BAND=3 NSA_HIP_DECODE_WIDE=2
