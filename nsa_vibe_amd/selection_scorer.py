@@ -44,7 +44,7 @@ def workspace(dev: torch.device, nbytes: int, tag: str = "ws") -> Optional[torch
     nsa/core/attention_kernels.py:25-26,64-103; keyed by stream here so concurrent streams cannot race on it)."""
     if nbytes <= 0:
         return None
-    key = (tag, dev.index, torch.cuda.current_stream(dev).cuda_stream)  # per stream: two streams never share scratch
+    key = (tag, dev.index, _stream(dev))  # per stream: two streams never share scratch
     buf = _WS.get(key)
     # grown on demand; given back when a much smaller shape follows a big one (the key-split records of a 64k prefill are gigabytes)
     if buf is None or buf.numel() < nbytes or buf.numel() > max(4 * nbytes, 256 << 20):

@@ -773,6 +773,8 @@ def test_key_split_rows_at_the_end_of_a_longer_context(nv, orc, tune):
     pos = (S_kv - S + torch.arange(S, device="cuda", dtype=torch.int32))[None, :, None]
     rg[..., 12, 0] = (pos // 64) * 64  # the row's own partial block
     rg[..., 12, 1] = pos + 1
+    tune("SEL_ROWS", -1), tune("SEL_BLOCKS", -1)  # (the block form at its default width: the only one with a key-split form -- a suite run
+    # under NSA_HIP_SEL_ROWS / NSA_HIP_SEL_BLOCKS would otherwise compare the plain walk with itself in the last assertion)
     tune("SEL_FLAT", 0), tune("SEL_KSPLIT", 0)
     plain = nv.selection_attention_hip(Q, K, V, rg)
     tune("SEL_KSPLIT", 1), tune("SEL_KSPLIT_T1", 2600), tune("SEL_KSPLIT_T2", 2800)
