@@ -93,8 +93,13 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
     x8 qf[3][4];
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
+        // pair of row R = 32 n + r: the 48 rows a lane half owns in the second sweep (rows 8 gq + 4 half + e of every 32: bit 2 of R = the
+        // half) are 8 COMPLETE queries in the lane's register order -- index within the half idx = 4 (R >> 3) + (R & 3) -> query 8 half + idx / 6,
+        // head idx % 6 -- so the Eq.10 head sum needs no exchange between the lane halves (rows as R / 6, R % 6: two permlane swaps and two
+        // DPP adds per four queries, 60 vector operations per half tile against 40 now)
         const int R = 32 * n + r;
-        const int t = tw + R / HC, hh = R % HC;
+        const int ridx = ((R >> 3) << 2) | (R & 3);
+        const int t = tw + 8 * ((R >> 2) & 1) + ridx / HC, hh = ridx % HC;
         const bool ok = t < P.S;
         const T *qr = (const T *)P.Q + ((((int64_t)b * P.S + (ok ? t : 0)) * P.G + g) * HC + hh) * (int64_t)D;
 #pragma unroll
@@ -270,9 +275,10 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
     // left the L2 with half-written sectors: 6.0 GB of writes for 4.3 GB of scores at 64k x 16).
     float *st_w = &stn[wave][8 * half][0];
     const int q2 = r >> 4, jb = r & 15;
-    // query of (rd, this lane) = tw + 4 rd + q2 + 2 half: byte offset of its block jb in the sequence's p_grp for rd = 0, then a uniform stride
-    const unsigned poff0 = ((unsigned)(((tw + q2 + 2 * half) * P.G + g) * P.S_sel) + (unsigned)jb) * 4u;
-    const unsigned rdstride = (unsigned)(4 * P.G * P.S_sel) * 4u;
+    // query of (rd, this lane) = tw + 8 half + 2 rd + q2 (ring row 8 half + z holds query 8 half + z of the wave): byte offset of its block jb in
+    // the sequence's p_grp for rd = 0, then a uniform stride
+    const unsigned poff0 = ((unsigned)(((tw + q2 + 8 * half) * P.G + g) * P.S_sel) + (unsigned)jb) * 4u;
+    const unsigned rdstride = (unsigned)(2 * P.G * P.S_sel) * 4u;
     if (lane < 16) stn[wave][lane][127] = 0.f;  // column -1 of the first half tile: outside [0, S_cmp), dropped
     if (tiles2 > 0) {
         load_tile(0);
@@ -325,28 +331,13 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                     for (int e = 0; e < 4; ++e)
                         if (dead) p[k][e] = 0.f;
             }
-            // Eq.10.  Rows of the wave in chunks of 4: the lower lane half owns the even chunks, the upper half the odd ones.  Per 6 chunks (24
-            // rows = 4 queries) and register triple (A, B, C) = chunks (3 m, 3 m + 1, 3 m + 2) of this half:
-            //   query 4m   = lower A[0..3]            + upper A[0..1]        query 4m+1 = lower B[0..3] + upper A[2..3]
-            //   query 4m+2 = upper B[0..3]            + lower C[0..1]        query 4m+3 = upper C[0..3] + lower C[2..3]
-            // so the lower half finishes 4m and 4m+1, the upper half 4m+2 and 4m+3, and two half swaps carry the 2-row parts.
+            // Eq.10: the lane's 48 values in register order (chunk k, element e) are rows idx = 4 k + e of its half = queries idx / 6 (see the Q
+            // fragments): six consecutive values per query, summed as ((a + b) + (c + d)) + (e + f)
             float zs[8];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float(&A)[4] = p[3 * m], (&Bc)[4] = p[3 * m + 1], (&C)[4] = p[3 * m + 2];
-                const float u = A[0] + A[1], v = A[2] + A[3], w = u + v;
-                const float sb = (Bc[0] + Bc[1]) + (Bc[2] + Bc[3]);
-                const float u2 = C[0] + C[1], v2 = C[2] + C[3], w2 = u2 + v2;
-                // swap(a, b): [0] = (lower a, lower b), [1] = (upper a, upper b)
-                const auto su = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u2), false, false);
-                const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v2), false, false);
-                float z1 = w + __uint_as_float(su[1]);   // lower half: query 4m
-                float z2 = sb + __uint_as_float(sv[1]);  // lower half: query 4m+1
-                // upper half (rows 2, 3 of the wave): query 4m+2 = sb + lower u2, query 4m+3 = w2 + lower v2
-                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf" : "+v"(z1) : "v"(__uint_as_float(su[0])), "v"(sb));
-                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf" : "+v"(z2) : "v"(__uint_as_float(sv[0])), "v"(w2));
-                zs[2 * m] = z1;
-                zs[2 * m + 1] = z2;
+            for (int z = 0; z < 8; ++z) {
+                auto pf = [&](int i) -> float { return p[(6 * z + i) >> 2][(6 * z + i) & 3]; };
+                zs[z] = ((pf(0) + pf(1)) + (pf(2) + pf(3))) + (pf(4) + pf(5));
             }
             {
 #pragma unroll
@@ -365,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void scores_mfma32_kernel(ScoresMfmaParams 
                         y += x[1];
                         y += x[2];
                         y = __builtin_fmaf(0.5f, x[3], y);
-                        if (mine && (all_rows || tw + 4 * rd + q2 + 2 * half < P.S))
+                        if (mine && (all_rows || tw + 8 * half + 2 * rd + q2 < P.S))
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), pg_rs, (int)poff0, (int)(64u * (unsigned)pr + (unsigned)rd * rdstride), 0);
                     }
                     wave_lds_fence();  // the next pair overwrites the other half of the ring only after these reads
