@@ -326,6 +326,8 @@ __device__ __forceinline__ void band_attn_body(const BandAttnParams &P, const un
         if (mg && mg->on) {
             // ---- merge of the unit's nsplit records (waves wave - sp .. of this workgroup), heads dealt over the unit's waves; one lane per
             // column.  The decode finish kernel's arithmetic (layer_fused.hip: 16 clamped steps, weights of the missing splits 0).
+            // (every live wave of the workgroup arrives here exactly once: waves beyond the last unit have returned above -- a terminated
+            // wave no longer counts for s_barrier -- and a wave without tiles or without used slots still runs through the epilogue)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int ns = P.nsplit;
             const float *u0 = (const float *)(smem + (size_t)(wave - sp) * (2 * G_::TILE_BYTES));
