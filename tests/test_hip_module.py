@@ -309,7 +309,7 @@ def test_decode_band_branches_on_the_step_launch_equal_their_own_launch(B, S, n_
     x = torch.randn(B, S + n_dec, 768, device="cuda", dtype=dtype)
     forms = [dict(DECODE_BAND=0), dict(DECODE_BAND=1), dict(DECODE_BAND=2), dict(DECODE_BAND=3), dict(DECODE_BAND=-1, DECODE_SPLIT=2),
              dict(DECODE_BAND=-1, DECODE_WIDE=2)]
-    outs = []
+    outs, side = [], []
     with torch.no_grad():
         for sw in forms:
             for k in ("DECODE_SPLIT", "DECODE_WIDE"):
@@ -322,6 +322,11 @@ def test_decode_band_branches_on_the_step_launch_equal_their_own_launch(B, S, n_
                 y, kv = m(x[:, t: t + 1], kv, prefill=False)
                 dec.append(y)
             outs.append(torch.cat(dec, dim=1))
+            side.append((m._last_gates.clone(), m._last_ranges.clone()))
+    # the gates (evaluated by the finish kernel / by the sliding branch's workgroup) and the selected ranges of the last step: same bits in
+    # every route of the same step form
+    for gts, rgs in side[1:4]:
+        assert torch.equal(gts, side[0][0]) and torch.equal(rgs, side[0][1])
     ref = outs[0].float()
     scale = max(1.0, ref.abs().max().item())
     assert torch.isfinite(ref).all()
